@@ -1,0 +1,154 @@
+/*
+ * sickle_amd.h -- C ABI of libsickle_amd.so: the MI355X (gfx950) replacement for the
+ * per-batch quality scan of pentalpha/sickle.
+ *
+ * The reference has no FFI; the seam this ABI fills is what its worker threads do for
+ * one batch:
+ *   Trim_Single::processing_thread   reference src/trim_single.cpp:357-372
+ *   Trim_Paired::processing_thread   reference src/trim_paired.cpp:483-504
+ * i.e. `saved_cutsites[i] = sliding_window(*queue[i])` for every read of the batch, with
+ *   Abstract_Trimmer::sliding_window  reference src/trim.cpp:3-116
+ *   Abstract_Trimmer::get_quality_num reference src/trim.cpp:118-140
+ * Conventions kept from the reference: the result per read is its `cutsites` pair
+ * (src/sickle.h:93-96), a read is kept iff three >= 0 (src/trim_single.cpp:368), and a
+ * quality character outside the encoding's range is fatal (src/trim.cpp:129-137).
+ * Conventions changed because this is a library: the caller owns every buffer, nothing
+ * is malloc'd per read, and the range error is RETURNED (sk_err) instead of exit(1) --
+ * the host pipeline prints the reference's message and exits.
+ *
+ * There is no CPU fallback: every entry point that computes runs the HIP kernels and
+ * fails (SK_ENODEV / SK_EHIP) when no gfx950 device is usable.
+ *
+ * Batch layout (struct-of-arrays, packed by the ingest side):
+ *   ragged      : offsets != NULL; read r = bytes [offsets[r], offsets[r+1]) of qual (and seq)
+ *   fixed stride: offsets == NULL; read r = bytes [r*stride, r*stride + len_r) with
+ *                 len_r = lengths ? lengths[r] : read_len.  The fast tiled kernel is used
+ *                 when stride % 8 == 0 and stride <= SK_TILE_MAX_STRIDE and the base
+ *                 pointers are 16-byte aligned; any other fixed-stride batch goes through
+ *                 the general kernel.
+ * seq is only read when params->trunc_n != 0 (the N rule, src/trim.cpp:86-98) and may be
+ * NULL otherwise.
+ */
+#ifndef SICKLE_AMD_H
+#define SICKLE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_ABI_VERSION 1
+
+/* quality_type, reference src/sickle.h:61-66 */
+enum { SK_PHRED = 0, SK_SANGER = 1, SK_SOLEXA = 2, SK_ILLUMINA = 3 };
+
+/* return codes */
+enum {
+    SK_OK = 0,
+    SK_ERANGE = 1, /* a quality char outside the encoding's range was read: *err is filled */
+    SK_EINVAL = -1,
+    SK_ENODEV = -2, /* no usable gfx950 device */
+    SK_EHIP = -3,   /* a HIP runtime call failed: see sk_last_error() */
+    SK_EBUSY = -4   /* slot still in flight */
+};
+
+#define SK_TILE_MAX_STRIDE 640u /* 4 waves x 64 reads x 640 B = the 160 KiB LDS of one CU */
+#define SK_MAX_READ_LEN (1u << 24)
+
+/* the config ints of Abstract_Trimmer, reference src/trim.h:16-20 */
+typedef struct {
+    int32_t qualtype;         /* SK_SANGER / SK_SOLEXA / SK_ILLUMINA (SK_PHRED accepted) */
+    int32_t qual_threshold;   /* -q, >= 0 */
+    int32_t length_threshold; /* -l, >= 0 */
+    int32_t no_fiveprime;     /* -x */
+    int32_t trunc_n;          /* -n */
+} sk_params;
+
+/* == reference `cutsites`, src/sickle.h:93-96; discarded reads are (-1,-1) */
+typedef struct {
+    int32_t five;
+    int32_t three;
+} sk_cut;
+
+/* the first out-of-range quality char: what src/trim.cpp:130-135 prints */
+typedef struct {
+    uint32_t read; /* lowest erroring read index in the batch */
+    uint32_t pos;  /* 0-based position in the read (the reference prints pos+1) */
+    int32_t ch;    /* (int)(char) value, i.e. bytes >= 0x80 are negative */
+} sk_err;
+
+typedef struct {
+    const uint8_t *qual;
+    const uint8_t *seq;      /* NULL unless trunc_n */
+    const uint64_t *offsets; /* n_reads+1 entries, or NULL */
+    uint32_t stride;         /* fixed-stride layout only */
+    uint32_t read_len;       /* fixed-stride layout with lengths == NULL */
+    const uint32_t *lengths; /* fixed-stride layout, per-read lengths, or NULL */
+    uint64_t n_reads;
+} sk_batch;
+
+typedef struct sk_ctx sk_ctx;
+
+/* {offset, min, max} of an encoding, reference src/sickle.h:85-91; NULL if qualtype invalid */
+const int32_t *sk_quality_constants(int32_t qualtype);
+/* "Phred" / "Sanger" / "Solexa" / "Illumina", reference src/sickle.h:68-73 */
+const char *sk_typename(int32_t qualtype);
+int sk_abi_version(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int sk_device_count(void);
+
+/* One context per device and host thread of use; owns two streams (compute, copy) and
+ * `slots` staging slots for the asynchronous host path.  device < 0 -> current device. */
+int sk_create(int device, int slots, sk_ctx **out);
+void sk_destroy(sk_ctx *ctx);
+const char *sk_last_error(const sk_ctx *ctx);
+int sk_device(const sk_ctx *ctx);
+
+/* pinned host memory for batches and cut arrays (plain malloc'd memory also works with
+ * sk_submit, only slower) */
+void *sk_host_alloc(sk_ctx *ctx, size_t bytes);
+void sk_host_free(sk_ctx *ctx, void *p);
+
+/*
+ * Device-resident batch: every pointer in *batch and `out` is a DEVICE pointer.  Enqueues
+ * the scan on `hip_stream` (a hipStream_t; NULL = the context's compute stream) and
+ * returns without waiting.  out[r] is written for every read; the error word is reset by
+ * a memset node ahead of the kernel.
+ */
+int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *batch,
+                         sk_cut *out, void *hip_stream);
+/* Waits for the stream and reports the range error of the most recent sk_scan_device_async
+ * on it: SK_OK, or SK_ERANGE with *err filled. */
+int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err);
+
+/*
+ * Host batch, synchronous: H2D, scan, D2H.  What processing_thread does for one batch.
+ * Returns SK_OK, SK_ERANGE (*err filled; `out` then holds the cuts of the reads the device
+ * still scanned, the caller is expected to abort like the reference does) or < 0.
+ */
+int sk_trim_batch(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, sk_cut *out,
+                  sk_err *err);
+
+/*
+ * Host batch, asynchronous, double-buffered: sk_submit copies the batch to the device on
+ * the copy stream, scans it on the compute stream and copies the cuts back into `out`;
+ * sk_wait blocks until that slot is done.  The caller keeps *batch's buffers and `out`
+ * alive and untouched in between.  With slots >= 2 the H2D copy of one batch overlaps the
+ * scan of the previous one.
+ */
+int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *batch, sk_cut *out);
+int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
+
+/* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile),
+ * 2 = general (wave per read).  For tests and bench labels. */
+int sk_kernel_for(const sk_batch *batch);
+
+/* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */
+const char *sk_kernel_name(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SICKLE_AMD_H */

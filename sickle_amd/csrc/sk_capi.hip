@@ -1,0 +1,409 @@
+// sk_capi.hip -- the C ABI of include/sickle_amd.h over the kernels of sk_kernels.hip.
+// HIP only: there is no CPU path behind these entry points.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "sickle_amd.h"
+#include "sk_device.h"
+
+namespace {
+
+// reference src/sickle.h:85-91
+const int32_t kQualityConstants[4][3] = {
+    {0, 4, 60},    // PHRED
+    {33, 33, 126}, // SANGER
+    {64, 58, 112}, // SOLEXA
+    {64, 64, 110}, // ILLUMINA
+};
+// reference src/sickle.h:68-73
+const char *const kTypeNames[4] = {"Phred", "Sanger", "Solexa", "Illumina"};
+
+constexpr unsigned long long kNoError = ~0ull;
+
+struct Slot {
+    bool busy = false;
+    uint8_t *d_qual = nullptr, *d_seq = nullptr;
+    size_t cap_bytes = 0;
+    uint64_t *d_offsets = nullptr;
+    uint32_t *d_lengths = nullptr;
+    size_t cap_reads = 0;
+    sk_cut_dev *d_out = nullptr;
+    unsigned long long *d_err = nullptr; // device error word of this slot
+    unsigned long long *h_err = nullptr; // pinned copy
+    hipEvent_t copied = nullptr;         // H2D done (copy stream)
+    hipEvent_t finished = nullptr;       // D2H of cuts + error word done (compute stream)
+};
+
+} // namespace
+
+struct sk_ctx {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t compute = nullptr, copy = nullptr;
+    unsigned long long *d_err = nullptr; // error word of the device-resident path
+    unsigned long long *h_err = nullptr;
+    std::vector<Slot> slots;
+    char last_error[512] = {0};
+};
+
+namespace {
+
+void set_error(sk_ctx *ctx, const char *fmt, ...)
+{
+    if (!ctx) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->last_error, sizeof ctx->last_error, fmt, ap);
+    va_end(ap);
+}
+
+#define SK_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error((ctx), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SK_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *a)
+{
+    if (!p || !b) return SK_EINVAL;
+    if (p->qualtype < 0 || p->qualtype > 3) {
+        set_error(ctx, "invalid qualtype %d", p->qualtype);
+        return SK_EINVAL;
+    }
+    if (p->qual_threshold < 0 || p->length_threshold < 0) {
+        set_error(ctx, "thresholds must be >= 0"); // reference src/trim_single.cpp:124,132
+        return SK_EINVAL;
+    }
+    if (b->n_reads > 0 && !b->qual) {
+        set_error(ctx, "qual is NULL");
+        return SK_EINVAL;
+    }
+    if (p->trunc_n && b->n_reads > 0 && !b->seq) {
+        set_error(ctx, "trunc_n needs seq");
+        return SK_EINVAL;
+    }
+    if (!b->offsets) {
+        if (b->stride == 0 || (!b->lengths && b->read_len > b->stride)) {
+            set_error(ctx, "fixed-stride batch: need stride >= read_len > 0");
+            return SK_EINVAL;
+        }
+        if (b->read_len > SK_MAX_READ_LEN) return SK_EINVAL;
+    }
+    if (b->n_reads >= (1ull << 32)) {
+        set_error(ctx, "more than 2^32-1 reads in one batch");
+        return SK_EINVAL;
+    }
+    const int32_t *k = kQualityConstants[p->qualtype];
+    // Every threshold above the largest representable quality (max - offset <= 93) behaves the
+    // same: no window and no char can reach it.  Clamping keeps the device integers small.
+    const int32_t qthr = p->qual_threshold > 127 ? 127 : p->qual_threshold;
+    a->n_reads = b->n_reads;
+    a->stride = b->stride;
+    a->read_len = b->read_len;
+    a->qmin = k[1];
+    a->qmax = k[2];
+    a->craw = qthr + k[0];
+    a->cthr = a->craw > 128 ? 128 : a->craw;
+    a->cthr_raw = a->craw;
+    a->lthr = p->length_threshold;
+    a->no5 = p->no_fiveprime ? 1 : 0;
+    a->truncn = p->trunc_n ? 1 : 0;
+    return SK_OK;
+}
+
+bool tile_eligible(const sk_batch *b)
+{
+    return !b->offsets && b->stride % 8 == 0 && b->stride >= 8 && b->stride <= SK_TILE_MAX_STRIDE &&
+           (reinterpret_cast<uintptr_t>(b->qual) & 15) == 0 && (!b->seq || (reinterpret_cast<uintptr_t>(b->seq) & 15) == 0);
+}
+
+// enqueue: reset error word, kernel.  All pointers are device pointers.
+int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_dev *out, unsigned long long *d_err,
+                 hipStream_t stream)
+{
+    SK_HIP(ctx, hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), stream));
+    if (a->n_reads == 0) return SK_OK;
+    const uint8_t *seq = a->truncn ? b->seq : nullptr;
+    if (tile_eligible(b))
+        SK_HIP(ctx, sk_launch_tile(b->qual, seq, b->lengths, out, d_err, a, ctx->cu_count, stream));
+    else
+        SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, a, ctx->cu_count, stream));
+    return SK_OK;
+}
+
+int decode_error(unsigned long long word, sk_err *err)
+{
+    if (word == kNoError) return SK_OK;
+    if (err) {
+        err->read = (uint32_t)(word >> 32);
+        err->pos = (uint32_t)((word >> 8) & 0xffffffu);
+        err->ch = (int32_t)(int8_t)(word & 0xff);
+    }
+    return SK_ERANGE;
+}
+
+size_t batch_bytes(const sk_batch *b)
+{
+    // bytes of qual (and seq) the batch spans on the host
+    if (b->n_reads == 0) return 0;
+    if (b->offsets) return (size_t)b->offsets[b->n_reads];
+    return (size_t)b->n_reads * b->stride;
+}
+
+int grow_slot(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq, bool need_off, bool need_len)
+{
+    const size_t pad = 256; // the tiled kernel's last 16-byte chunk never crosses this
+    if (bytes + pad > s.cap_bytes || (need_seq && !s.d_seq)) {
+        size_t cap = bytes + pad > s.cap_bytes ? (bytes + pad) + (bytes >> 3) : s.cap_bytes;
+        if (s.d_qual) (void)hipFree(s.d_qual);
+        if (s.d_seq) (void)hipFree(s.d_seq);
+        s.d_qual = s.d_seq = nullptr;
+        s.cap_bytes = 0;
+        SK_HIP(ctx, hipMalloc(&s.d_qual, cap));
+        if (need_seq) SK_HIP(ctx, hipMalloc(&s.d_seq, cap));
+        s.cap_bytes = cap;
+    }
+    if (reads + 1 > s.cap_reads || (need_off && !s.d_offsets) || (need_len && !s.d_lengths)) {
+        size_t cap = reads + 1 > s.cap_reads ? (reads + 1) + (reads >> 3) : s.cap_reads;
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_offsets) (void)hipFree(s.d_offsets);
+        if (s.d_lengths) (void)hipFree(s.d_lengths);
+        s.d_out = nullptr;
+        s.d_offsets = nullptr;
+        s.d_lengths = nullptr;
+        s.cap_reads = 0;
+        SK_HIP(ctx, hipMalloc(&s.d_out, cap * sizeof(sk_cut_dev)));
+        if (need_off) SK_HIP(ctx, hipMalloc(&s.d_offsets, cap * sizeof(uint64_t)));
+        if (need_len) SK_HIP(ctx, hipMalloc(&s.d_lengths, cap * sizeof(uint32_t)));
+        s.cap_reads = cap;
+    }
+    return SK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const int32_t *sk_quality_constants(int32_t qualtype)
+{
+    return (qualtype < 0 || qualtype > 3) ? nullptr : kQualityConstants[qualtype];
+}
+
+const char *sk_typename(int32_t qualtype) { return (qualtype < 0 || qualtype > 3) ? nullptr : kTypeNames[qualtype]; }
+
+int sk_abi_version(void) { return SK_ABI_VERSION; }
+
+int sk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sk_create(int device, int slots, sk_ctx **out)
+{
+    if (!out) return SK_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SK_ENODEV;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return SK_ENODEV;
+    }
+    if (device >= n) return SK_ENODEV;
+    if (slots < 1) slots = 1;
+    if (slots > 16) slots = 16;
+    sk_ctx *ctx = new (std::nothrow) sk_ctx();
+    if (!ctx) return SK_EINVAL;
+    ctx->device = device;
+    auto fail = [&](int rc) {
+        fprintf(stderr, "sickle_amd: sk_create failed: %s\n", ctx->last_error);
+        sk_destroy(ctx);
+        return rc;
+    };
+#define SK_TRY(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error(ctx, "%s failed: %s", #call, hipGetErrorString(e_));              \
+            return fail(SK_EHIP);                                                       \
+        }                                                                               \
+    } while (0)
+    SK_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SK_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(ctx, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+        return fail(SK_ENODEV);
+    }
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
+    SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    SK_TRY(hipMalloc(&ctx->d_err, sizeof(unsigned long long)));
+    SK_TRY(hipHostMalloc(&ctx->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    *ctx->h_err = kNoError;
+    ctx->slots.resize((size_t)slots);
+    for (Slot &s : ctx->slots) {
+        SK_TRY(hipMalloc(&s.d_err, sizeof(unsigned long long)));
+        SK_TRY(hipHostMalloc(&s.h_err, sizeof(unsigned long long), hipHostMallocDefault));
+        SK_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        SK_TRY(hipEventCreateWithFlags(&s.finished, hipEventDisableTiming));
+    }
+#undef SK_TRY
+    *out = ctx;
+    return SK_OK;
+}
+
+void sk_destroy(sk_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->compute) (void)hipStreamSynchronize(ctx->compute);
+    if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
+    for (Slot &s : ctx->slots) {
+        if (s.d_qual) (void)hipFree(s.d_qual);
+        if (s.d_seq) (void)hipFree(s.d_seq);
+        if (s.d_offsets) (void)hipFree(s.d_offsets);
+        if (s.d_lengths) (void)hipFree(s.d_lengths);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_err) (void)hipFree(s.d_err);
+        if (s.h_err) (void)hipHostFree(s.h_err);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.finished) (void)hipEventDestroy(s.finished);
+    }
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+    delete ctx;
+}
+
+const char *sk_last_error(const sk_ctx *ctx) { return ctx ? ctx->last_error : "no context"; }
+int sk_device(const sk_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+void *sk_host_alloc(sk_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        set_error(ctx, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void sk_host_free(sk_ctx *ctx, void *p)
+{
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
+}
+
+int sk_kernel_for(const sk_batch *batch)
+{
+    if (!batch) return 0;
+    return tile_eligible(batch) ? 1 : 2;
+}
+
+const char *sk_kernel_name(int which)
+{
+    switch (which) {
+    case 1: return "sk_scan_tile_kernel";
+    case 2: return "sk_scan_wave_kernel";
+    default: return "";
+    }
+}
+
+int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, sk_cut *out, void *hip_stream)
+{
+    if (!ctx || !out) return SK_EINVAL;
+    sk_scan_args a;
+    int rc = make_args(ctx, params, batch, &a);
+    if (rc != SK_OK) return rc;
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->compute;
+    return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), ctx->d_err, stream);
+}
+
+int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err)
+{
+    if (!ctx) return SK_EINVAL;
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->compute;
+    SK_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SK_HIP(ctx, hipStreamSynchronize(stream));
+    return decode_error(*ctx->h_err, err);
+}
+
+int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *batch, sk_cut *out)
+{
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || !batch || (!out && batch->n_reads)) return SK_EINVAL;
+    Slot &s = ctx->slots[(size_t)slot];
+    if (s.busy) return SK_EBUSY;
+    sk_scan_args a;
+    int rc = make_args(ctx, params, batch, &a);
+    if (rc != SK_OK) return rc;
+    SK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = batch_bytes(batch);
+    const size_t n = (size_t)batch->n_reads;
+    if (!batch->offsets && batch->lengths) {
+        for (size_t r = 0; r < n; ++r)
+            if (batch->lengths[r] > batch->stride) {
+                set_error(ctx, "lengths[%zu] = %u exceeds stride %u", r, batch->lengths[r], batch->stride);
+                return SK_EINVAL;
+            }
+    }
+    rc = grow_slot(ctx, s, bytes, n, a.truncn != 0, batch->offsets != nullptr, batch->lengths != nullptr);
+    if (rc != SK_OK) return rc;
+
+    // H2D on the copy stream (overlaps the previous slot's kernel on the compute stream)
+    if (bytes) {
+        SK_HIP(ctx, hipMemcpyAsync(s.d_qual, batch->qual, bytes, hipMemcpyHostToDevice, ctx->copy));
+        if (a.truncn) SK_HIP(ctx, hipMemcpyAsync(s.d_seq, batch->seq, bytes, hipMemcpyHostToDevice, ctx->copy));
+    }
+    if (batch->offsets)
+        SK_HIP(ctx, hipMemcpyAsync(s.d_offsets, batch->offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy));
+    if (!batch->offsets && batch->lengths && n)
+        SK_HIP(ctx, hipMemcpyAsync(s.d_lengths, batch->lengths, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy));
+    SK_HIP(ctx, hipEventRecord(s.copied, ctx->copy));
+    SK_HIP(ctx, hipStreamWaitEvent(ctx->compute, s.copied, 0));
+
+    sk_batch dev = *batch;
+    dev.qual = s.d_qual;
+    dev.seq = a.truncn ? s.d_seq : nullptr;
+    dev.offsets = batch->offsets ? s.d_offsets : nullptr;
+    dev.lengths = (!batch->offsets && batch->lengths) ? s.d_lengths : nullptr;
+    rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute);
+    if (rc != SK_OK) return rc;
+    if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));
+    SK_HIP(ctx, hipMemcpyAsync(s.h_err, s.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->compute));
+    SK_HIP(ctx, hipEventRecord(s.finished, ctx->compute));
+    s.busy = true;
+    return SK_OK;
+}
+
+int sk_wait(sk_ctx *ctx, int slot, sk_err *err)
+{
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return SK_EINVAL;
+    Slot &s = ctx->slots[(size_t)slot];
+    if (!s.busy) return SK_EINVAL;
+    SK_HIP(ctx, hipEventSynchronize(s.finished));
+    s.busy = false;
+    return decode_error(*s.h_err, err);
+}
+
+int sk_trim_batch(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, sk_cut *out, sk_err *err)
+{
+    int rc = sk_submit(ctx, 0, params, batch, out);
+    if (rc != SK_OK) return rc;
+    return sk_wait(ctx, 0, err);
+}
+
+} // extern "C"

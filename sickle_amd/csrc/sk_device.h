@@ -1,0 +1,38 @@
+// sk_device.h -- shared between the kernels (sk_kernels.hip) and the C-ABI layer (sk_capi.hip).
+#ifndef SK_DEVICE_H
+#define SK_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SK_TILE_THREADS 256
+#define SK_TILE_WAVES (SK_TILE_THREADS / 64)
+#define SK_TILE_SLACK 128u /* bytes a lane may read past its tile (the lead stream runs ahead) */
+#define SK_WAVE_THREADS 256
+#define SK_LDS_PER_CU (160u * 1024u)
+
+struct sk_cut_dev {
+    int32_t five, three;
+};
+
+// Scalar arguments of one scan, derived on the host from sk_params (+ the batch shape).
+struct sk_scan_args {
+    uint64_t n_reads;
+    uint32_t stride;   // bytes between reads (fixed-stride layouts)
+    uint32_t read_len; // uniform read length (fixed-stride, lengths == NULL)
+    int32_t qmin, qmax; // legal char range of the encoding (reference src/sickle.h:85-91)
+    int32_t craw;      // qual_threshold + offset: the threshold on raw chars (window: craw * w)
+    int32_t cthr;      // min(craw, 128), for the byte-parallel compares
+    int32_t cthr_raw;  // == craw (scalar compares of the wave kernel)
+    int32_t lthr;      // length_threshold
+    int32_t no5;       // -x
+    int32_t truncn;    // -n
+};
+
+extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
+                                     sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
+                                     int cu_count, hipStream_t stream);
+extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
+                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
+#endif

@@ -1,0 +1,432 @@
+// sk_kernels.hip -- the quality-scan kernels for gfx950 (CDNA4, wave64).
+//
+// What is computed, per read, is exactly Abstract_Trimmer::sliding_window of the
+// reference (src/trim.cpp:3-116) with get_quality_num's range check (src/trim.cpp:118-140);
+// how it is computed is not: the reference walks the read once with a rolling sum and
+// early breaks, the kernels use the closed form
+//     S_i   = sum of the w = max(L/10, L if L<10) chars of window i      (0 <= i <= L-w)
+//     i0    = first i with S_i >= T        (T = (qthr+offset)*w, on raw chars)   -> 5' window
+//     i1    = first i >  i0 with S_i <  T  (i >= 0 with -x)                      -> 3' window
+//     five  = first j >= i0 with c[j] >= qthr+offset ; three = first j >= i1 with c[j] < qthr+offset
+// (the reference's double-precision average compares exactly like the integers), the N rule
+// and the length filter applied afterwards, and the range error raised iff the first bad
+// char lies in the part of the read the reference would have touched: [0, i1 + w) if the
+// 3' break fired, the whole read otherwise, nothing if L < length_threshold.
+//
+// Two kernels:
+//   sk_scan_tile_kernel   fixed-stride batches.  One LANE per read, one wavefront per
+//                         64-read tile.  The tile (64*stride contiguous bytes) goes HBM ->
+//                         LDS with global_load_lds_dwordx4 (fully coalesced, no VGPR round
+//                         trip); each lane then walks its own row in LDS 4 windows per
+//                         dword with byte-parallel arithmetic: signed byte differences
+//                         lead-trail, v_dot4c to advance the running sum, v_alignbit to
+//                         shift the sign bit of (S_i - T) into a 32-window mask.
+//   sk_scan_wave_kernel   any layout (ragged offsets, odd strides, long reads).  One
+//                         WAVEFRONT per read; each lane owns a contiguous run of windows,
+//                         seeds its window sum directly and rolls it in a register; the
+//                         per-lane first-hits are combined with wave min-reductions.
+// No MFMA: this is byte streaming, HBM-bound (algorithmic bytes: L + 8 per read, 2L + 8 with -n).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sk_device.h"
+
+namespace {
+
+constexpr uint32_t H4 = 0x80808080u;
+constexpr int INF = 0x7fffffff;
+
+__device__ __forceinline__ uint32_t splat(uint32_t b) { return b * 0x01010101u; }
+
+// bit 7 of each byte set iff that byte (assumed < 128) is >= the byte of c4 (each <= 128)
+__device__ __forceinline__ uint32_t ge_flags(uint32_t x, uint32_t c4) { return ((x | H4) - c4) & H4; }
+
+// bit 7 of each byte set iff that byte is outside [min, max] (or >= 128):  the range check of
+// reference src/trim.cpp:129, four chars at a time.  min4 = splat(min), hi4 = splat(127 - max).
+__device__ __forceinline__ uint32_t bad_flags(uint32_t x, uint32_t min4, uint32_t hi4)
+{
+    uint32_t lo_ok = (x | H4) - min4;  // bit7 set iff byte >= min
+    uint32_t hi_bad = (x & ~H4) + hi4; // bit7 set iff (byte & 127) > max
+    return (~lo_ok | hi_bad | x) & H4;
+}
+
+// bit 7 of each byte set iff that byte == the byte of c4 (exact for the LOWEST set flag)
+__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t c4)
+{
+    uint32_t y = x ^ c4;
+    return (y - 0x01010101u) & ~y & H4;
+}
+
+// flags of bytes [n, 4) cleared, n in 0..4
+__device__ __forceinline__ uint32_t keep_first(uint32_t flags, int n)
+{
+    return n >= 4 ? flags : (n <= 0 ? 0u : flags & ((1u << (8 * n)) - 1u));
+}
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ void report_error(unsigned long long *errword, uint64_t read, int pos, int ch)
+{
+    // lowest read index wins; ties (same read) resolve to the lowest position
+    unsigned long long key = ((unsigned long long)read << 32) | ((unsigned long long)(uint32_t)pos << 8) |
+                             (unsigned long long)(uint32_t)(ch & 0xff);
+    atomicMin(errword, key);
+}
+
+using gptr_t = const __attribute__((address_space(1))) void *;
+using lptr_t = __attribute__((address_space(3))) void *;
+
+// Copies `bytes` (multiple of 4) from global `src` (16-byte aligned) to the wave-private LDS
+// region `dst` with LDS-DMA; the LDS image is byte-identical to the global one.
+__device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, uint32_t bytes, int lane)
+{
+    const uint32_t nfull = bytes >> 4;
+    for (uint32_t c0 = 0; c0 < nfull; c0 += 64) { // c0 is wave-uniform: one 1 KiB piece per trip
+        if (c0 + lane < nfull)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(c0 + lane) * 16), (lptr_t)(dst + c0 * 16),
+                                             16, 0, 0);
+    }
+    const uint32_t tail = (bytes & 15u) >> 2; // 0..3 dwords after the last full 16-byte chunk
+    if ((uint32_t)lane < tail)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)nfull * 16 + lane * 4), (lptr_t)(dst + nfull * 16),
+                                         4, 0, 0);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// Tiled kernel: lane per read.
+// LDS per wave: 64*stride bytes of tile + SK_TILE_SLACK bytes the lead stream may over-read.
+// ------------------------------------------------------------------------------------------
+template <bool UNIFORM, bool HAS_SEQ>
+__global__ void __launch_bounds__(SK_TILE_THREADS)
+sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                    const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
+                    unsigned long long *errword, sk_scan_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t stride = a.stride;
+    const uint32_t wave_lds = 64u * stride + SK_TILE_SLACK;
+    uint8_t *tile = lds + (size_t)wave * wave_lds;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
+
+    const uint64_t n_tiles = (a.n_reads + 63) >> 6;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * SK_TILE_WAVES + wave;
+    const uint64_t wave_count = (uint64_t)gridDim.x * SK_TILE_WAVES;
+
+    const uint32_t min4 = splat((uint32_t)a.qmin), hi4 = splat((uint32_t)(127 - a.qmax));
+    const uint32_t cthr4 = splat((uint32_t)a.cthr);
+
+    for (uint64_t t = wave_global; t < n_tiles; t += wave_count) {
+        const uint64_t r0 = t << 6;
+        const uint64_t r = r0 + lane;
+        const uint32_t rows = (uint32_t)min((uint64_t)64, a.n_reads - r0);
+        const uint32_t tile_bytes = rows * stride;
+
+        // the previous trip's LDS reads are complete (their results were consumed), so the
+        // buffer can be refilled; the fill is ordered before this trip's reads by vmcnt(0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tile_to_lds(qual + r0 * stride, tile, tile_bytes, lane);
+
+        const bool active = r < a.n_reads;
+        int L = 0;
+        if (active) L = UNIFORM ? (int)a.read_len : (int)min(lengths[r], stride);
+        // reference trim.cpp:21 -- shorter than -l: discarded before any quality is read
+        const bool scanned = active && L > 0 && L >= a.lthr;
+        if (!scanned) L = 0;
+        int w = L / 10; // trim.cpp:8 (int)(0.1*L) == L/10
+        if (w == 0) w = L; // trim.cpp:30
+        const int nwin = scanned ? L - w + 1 : 0;
+        const int m = w >> 2, sh = w & 3;
+        const int Lmax = UNIFORM ? (int)a.read_len : wave_max(L);
+        const int wmax = UNIFORM ? (Lmax / 10 ? Lmax / 10 : Lmax) : wave_max(w);
+        const int nwinmax = UNIFORM ? Lmax - wmax + 1 : wave_max(nwin);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- range check over the whole read (decided against the touched prefix below)
+        uint32_t bad = 0;
+        for (int k = 0; 4 * k < Lmax; ++k) bad |= keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
+
+        // ---- S_0 - T : trim.cpp:31-33
+        uint32_t acc = 0;
+        for (int k = 0; 4 * k < wmax; ++k) {
+            int nb = w - 4 * k;
+            uint32_t x = row[k];
+            x = nb >= 4 ? x : (nb <= 0 ? 0u : x & ((1u << (8 * nb)) - 1u));
+            acc = __builtin_amdgcn_sad_u8(x, 0u, acc);
+        }
+        int v = (int)acc - a.craw * w; // sign bit <=> window average below the threshold
+
+        // ---- all windows, 32 per trip: trim.cpp:34-81 without the breaks
+        bool found5 = a.no5 != 0; // with -x the 3' search starts at window 0 (trim.cpp:62)
+        bool done = false;
+        int i0 = 0, i1 = 0;
+        uint32_t lead_lo = row[m];
+        for (int base = 0; base < nwinmax; base += 32) {
+            uint32_t M = 0;
+            const int dw0 = base >> 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t y = row[dw0 + k];             // chars leaving the window
+                const uint32_t lead_hi = row[dw0 + k + m + 1];
+                const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, (uint32_t)sh); // chars entering
+                lead_lo = lead_hi;
+                const uint32_t d = ((x | H4) - y) ^ H4; // per byte: x - y as int8 (both < 128)
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                v = __builtin_amdgcn_sdot4((int)d, 0x00000001, v, false);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                v = __builtin_amdgcn_sdot4((int)d, 0x00000100, v, false);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                v = __builtin_amdgcn_sdot4((int)d, 0x00010000, v, false);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                v = __builtin_amdgcn_sdot4((int)d, 0x01000000, v, false);
+            }
+            // bit (31 - s) of M: window base+s is below the threshold
+            const int nv = nwin - base;
+            const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
+            uint32_t lt = M & vmask;
+            const uint32_t ge = ~M & vmask;
+            if (!found5) {
+                if (ge) { // trim.cpp:42
+                    const int p = __builtin_clz(ge);
+                    i0 = base + p;
+                    found5 = true;
+                    lt &= (p == 31) ? 0u : (~0u >> (p + 1));
+                } else {
+                    lt = 0;
+                }
+            }
+            if (found5 && !done && lt) { // trim.cpp:61
+                i1 = base + __builtin_clz(lt);
+                done = true;
+            }
+        }
+        const bool have5 = found5 && !a.no5;
+
+        // ---- the in-window searches: trim.cpp:46-51 and :65-70
+        int five = 0, three = L;
+        {
+            // 5': first char >= threshold at or after i0; 3': first char < threshold at or after i1.
+            // Both exist inside their window (its average is on that side of the threshold).
+            int k5 = i0 >> 2, k3 = i1 >> 2;
+            uint32_t g5 = have5 ? ge_flags(row[k5], cthr4) & (~0u << (8 * (i0 & 3))) : H4;
+            uint32_t g3 = done ? (ge_flags(row[k3], cthr4) ^ H4) & (~0u << (8 * (i1 & 3))) : H4;
+            const int trips = (wmax + 3) / 4 + 1;
+            for (int it = 0; it < trips; ++it) {
+                if (g5 == 0) { ++k5; g5 = ge_flags(row[k5], cthr4); }
+                if (g3 == 0) { ++k3; g3 = ge_flags(row[k3], cthr4) ^ H4; }
+            }
+            if (have5) five = 4 * k5 + ((__builtin_ctz(g5 | 0x80000000u)) >> 3);
+            if (done) three = 4 * k3 + ((__builtin_ctz(g3 | 0x80000000u)) >> 3);
+        }
+
+        // ---- range error: only if the first bad char is one the reference would have read
+        if (__builtin_amdgcn_ballot_w64(bad != 0)) {
+            if (bad != 0) {
+                const int touched = done ? i1 + w : L;
+                int p = 0;
+                for (int k = 0; 4 * k < L; ++k) {
+                    uint32_t f = keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
+                    if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
+                }
+                if (p < touched)
+                    report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * stride + p]));
+            }
+        }
+
+        // ---- the N rule: trim.cpp:86-98 (lowercase n: cut before it; only uppercase N: cut = -2)
+        if (HAS_SEQ) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tile_to_lds(seq + r0 * stride, tile, tile_bytes, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ni = INF, Ni = INF;
+            for (int k = 0; 4 * k < Lmax; ++k) {
+                const uint32_t x = row[k];
+                const uint32_t fn = keep_first(eq_flags(x, splat('n')), L - 4 * k);
+                const uint32_t fN = keep_first(eq_flags(x, splat('N')), L - 4 * k);
+                if (fn && ni == INF) ni = 4 * k + (__builtin_ctz(fn) >> 3);
+                if (fN && Ni == INF) Ni = 4 * k + (__builtin_ctz(fN) >> 3);
+            }
+            if (ni != INF) three = ni - 1;
+            else if (Ni != INF) three = -2;
+        }
+
+        // ---- trim.cpp:103-108
+        if (!scanned || (!found5 && !a.no5) || (three - five < a.lthr)) {
+            five = -1;
+            three = -1;
+        }
+        if (active) out[r] = sk_cut_dev{five, three};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// General kernel: wave per read, any layout.
+// ------------------------------------------------------------------------------------------
+template <bool HAS_SEQ>
+__global__ void __launch_bounds__(SK_WAVE_THREADS)
+sk_scan_wave_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                    const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
+                    sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * SK_WAVE_THREADS + threadIdx.x) >> 6;
+    const uint64_t wave_count = ((uint64_t)gridDim.x * SK_WAVE_THREADS) >> 6;
+
+    for (uint64_t r = wave_global; r < a.n_reads; r += wave_count) {
+        uint64_t off;
+        int L;
+        if (offsets) {
+            off = offsets[r];
+            L = (int)(offsets[r + 1] - off);
+        } else {
+            off = r * a.stride;
+            L = lengths ? (int)lengths[r] : (int)a.read_len;
+        }
+        const uint8_t *q = qual + off;
+        int five = -1, three = -1;
+        if (L > 0 && L >= a.lthr) { // trim.cpp:21
+            int w = L / 10;
+            if (w == 0) w = L;
+            const int nwin = L - w + 1;
+            const int T = a.craw * w;
+
+            // first bad char of the whole read (lanes stride the bytes, coalesced)
+            int pbad = INF;
+            for (int j = lane; j < L; j += 64) {
+                const int c = (int)(int8_t)q[j];
+                if ((c < a.qmin || c > a.qmax) && pbad == INF) pbad = j;
+            }
+            pbad = wave_min(pbad);
+
+            // lane owns windows [s, e): seeds the sum, then rolls it (trim.cpp:76-80)
+            const int per = (nwin + 63) >> 6;
+            const int s = lane * per;
+            const int e = min(nwin, s + per);
+            int fa = INF, fb = INF, fc = INF; // first >=T, first <T, first <T after fa
+            if (s < e) {
+                int tot = 0;
+                for (int j = 0; j < w; ++j) tot += q[s + j];
+                for (int i = s; i < e; ++i) {
+                    if (tot >= T) {
+                        if (fa == INF) fa = i;
+                    } else {
+                        if (fb == INF) fb = i;
+                        if (fa != INF && fc == INF) fc = i;
+                    }
+                    if (i + 1 < e) tot += (int)q[i + w] - (int)q[i];
+                }
+            }
+            const int i0 = a.no5 ? -1 : wave_min(fa);
+            const bool found5 = a.no5 || i0 != INF;
+            int cand = INF;
+            if (a.no5) cand = fb;
+            else if (i0 != INF && s < e) cand = (s > i0) ? fb : (fa == i0 ? fc : INF);
+            const int i1 = wave_min(cand);
+            const bool done = found5 && i1 != INF;
+
+            five = 0;
+            three = L;
+            if (!a.no5 && i0 != INF) { // trim.cpp:46-51
+                int hit = INF;
+                for (int j = lane; j < w && hit == INF; j += 64)
+                    if ((int)q[i0 + j] >= a.cthr_raw) hit = i0 + j;
+                five = wave_min(hit);
+                if (five == INF) five = 0;
+            }
+            if (done) { // trim.cpp:65-70
+                int hit = INF;
+                for (int j = lane; j < w && hit == INF; j += 64)
+                    if ((int)q[i1 + j] < a.cthr_raw) hit = i1 + j;
+                three = wave_min(hit);
+                if (three == INF) three = L;
+            }
+            const int touched = done ? i1 + w : L;
+            if (pbad < touched) {
+                if (lane == 0) report_error(errword, r, pbad, (int)(int8_t)q[pbad]);
+            }
+            if (HAS_SEQ) { // trim.cpp:86-98
+                const uint8_t *sq = seq + off;
+                int ni = INF, Ni = INF;
+                for (int j = lane; j < L; j += 64) {
+                    const uint8_t c = sq[j];
+                    if (c == 'n' && ni == INF) ni = j;
+                    if (c == 'N' && Ni == INF) Ni = j;
+                }
+                ni = wave_min(ni);
+                Ni = wave_min(Ni);
+                if (ni != INF) three = ni - 1;
+                else if (Ni != INF) three = -2;
+            }
+            if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
+                five = -1;
+                three = -1;
+            }
+        }
+        if (lane == 0) out[r] = sk_cut_dev{five, three};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (host side of this translation unit)
+// ------------------------------------------------------------------------------------------
+extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
+                                     sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
+                                     int cu_count, hipStream_t stream)
+{
+    const uint32_t wave_lds = 64u * a->stride + SK_TILE_SLACK;
+    const uint32_t lds_bytes = SK_TILE_WAVES * wave_lds;
+    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
+    const uint64_t blocks_needed = (n_tiles + SK_TILE_WAVES - 1) / SK_TILE_WAVES;
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    if (per_cu < 1) return hipErrorInvalidValue;
+    if (per_cu > 8) per_cu = 8;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    if (grid > blocks_needed) grid = blocks_needed;
+    if (grid == 0) return hipSuccess;
+    const bool uniform = lengths == nullptr;
+    const bool has_seq = a->truncn != 0;
+    auto launch = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_TILE_THREADS), lds_bytes, stream, qual, seq, lengths,
+                           out, errword, *a);
+        return hipGetLastError();
+    };
+    if (uniform) return has_seq ? launch(sk_scan_tile_kernel<true, true>) : launch(sk_scan_tile_kernel<true, false>);
+    return has_seq ? launch(sk_scan_tile_kernel<false, true>) : launch(sk_scan_tile_kernel<false, false>);
+}
+
+extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
+                                     const sk_scan_args *a, int cu_count, hipStream_t stream)
+{
+    const uint64_t waves_per_block = SK_WAVE_THREADS / 64;
+    const uint64_t blocks_needed = (a->n_reads + waves_per_block - 1) / waves_per_block;
+    uint64_t grid = (uint64_t)cu_count * 8;
+    if (grid > blocks_needed) grid = blocks_needed;
+    if (grid == 0) return hipSuccess;
+    if (a->truncn)
+        hipLaunchKernelGGL(sk_scan_wave_kernel<true>, dim3((unsigned)grid), dim3(SK_WAVE_THREADS), 0, stream, qual, seq,
+                           offsets, lengths, out, errword, *a);
+    else
+        hipLaunchKernelGGL(sk_scan_wave_kernel<false>, dim3((unsigned)grid), dim3(SK_WAVE_THREADS), 0, stream, qual,
+                           seq, offsets, lengths, out, errword, *a);
+    return hipGetLastError();
+}

@@ -1,0 +1,85 @@
+"""Seeded synthetic FASTQ generator (the workloads of SURVEY.md section 8d).
+
+Quality model per read: base Q ~ U[30,40], linear decay ~ U[0,0.25] per base, N(0, sigma=4)
+noise, clipped to [2,41]; a low-quality 5' head of 0..7 bases (Q=2) on every read; a fraction
+of bases replaced by 'N' (their quality forced to 2).  Encodings: sanger = phred+33,
+illumina = phred+64 (clip floor raised so that chars stay in 64..110)."""
+import numpy as np
+
+OFFSET = {"sanger": 33, "illumina": 64, "solexa": 64}
+
+
+def quality_matrix(rng, n, length, qualtype="sanger"):
+    """(n, length) uint8 matrix of quality CHARACTERS."""
+    base = rng.uniform(30.0, 40.0, size=(n, 1)).astype(np.float32)
+    decay = rng.uniform(0.0, 0.25, size=(n, 1)).astype(np.float32)
+    pos = np.arange(length, dtype=np.float32)[None, :]
+    q = base - decay * pos + rng.normal(0.0, 4.0, size=(n, length)).astype(np.float32)
+    q = np.clip(np.rint(q), 2, 41).astype(np.int16)
+    head = rng.integers(0, 8, size=(n, 1))
+    q[np.arange(length)[None, :] < head] = 2
+    return (q + OFFSET[qualtype]).astype(np.uint8)
+
+
+def sequence_matrix(rng, n, length, n_frac=0.002, lower_n_frac=0.0):
+    """(n, length) uint8 matrix of bases; n_frac of them 'N'; lower_n_frac of READS get one 'n'."""
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, length))]
+    seq = seq.copy()
+    seq[rng.random(size=(n, length)) < n_frac] = ord("N")
+    if lower_n_frac > 0:
+        rows = np.nonzero(rng.random(n) < lower_n_frac)[0]
+        seq[rows, rng.integers(0, length, size=rows.size)] = ord("n")
+    return seq
+
+
+def make_reads(seed, n, length, qualtype="sanger", n_frac=0.002, lower_n_frac=0.0):
+    """Fixed-length reads: (seq[n,length], qual[n,length]) uint8."""
+    rng = np.random.default_rng(seed)
+    qual = quality_matrix(rng, n, length, qualtype)
+    seq = sequence_matrix(rng, n, length, n_frac, lower_n_frac)
+    qual[(seq == ord("N")) | (seq == ord("n"))] = 2 + OFFSET[qualtype]
+    return seq, qual
+
+
+def make_ragged_reads(seed, n, lo, hi, qualtype="illumina", n_frac=0.003, lower_n_frac=0.05):
+    """Mixed-length reads lo..hi: (seq_bytes, qual_bytes, offsets[n+1] uint64), packed back to back."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, size=n)
+    seq_m, qual_m = make_reads(seed + 1, n, hi, qualtype, n_frac, lower_n_frac)
+    mask = np.arange(hi)[None, :] < lens[:, None]
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    return seq_m[mask], qual_m[mask], offsets
+
+
+def pack_fixed(mat, stride):
+    """Pad an (n, L) byte matrix to rows of `stride` bytes (zero fill) and flatten."""
+    n, length = mat.shape
+    out = np.zeros((n, stride), dtype=np.uint8)
+    out[:, :length] = mat
+    return out.reshape(-1)
+
+
+def fastq_bytes(seq, qual, prefix="SYN:", start=0, suffix="", plus="+"):
+    """FASTQ text for fixed-length matrices.  Header '@SYN:%09d' (+suffix), bare '+'."""
+    n = seq.shape[0]
+    parts = []
+    for i in range(n):
+        parts.append(b"@%s%09d%s\n" % (prefix.encode(), start + i, suffix.encode()))
+        parts.append(seq[i].tobytes())
+        parts.append(b"\n" + plus.encode() + b"\n")
+        parts.append(qual[i].tobytes())
+        parts.append(b"\n")
+    return b"".join(parts)
+
+
+def fastq_bytes_ragged(seq, qual, offsets, prefix="SYN:", start=0, suffix="", plus="+"):
+    parts = []
+    for i in range(len(offsets) - 1):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        parts.append(b"@%s%09d%s\n" % (prefix.encode(), start + i, suffix.encode()))
+        parts.append(seq[a:b].tobytes())
+        parts.append(b"\n" + plus.encode() + b"\n")
+        parts.append(qual[a:b].tobytes())
+        parts.append(b"\n")
+    return b"".join(parts)

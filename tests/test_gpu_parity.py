@@ -1,0 +1,229 @@
+"""GPU parity: the HIP kernels, called through the C ABI (libsickle_amd.so), against the
+oracle on the same inputs -- bit-exact (integer work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from sickle_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def key(qt, q, l, x, n):
+    return "%s_q%d_l%d_x%d_n%d" % (qt, q, l, int(x), int(n))
+
+
+def parse_key(k):
+    qt, q, l, x, n = k.split("_")
+    return qt, int(q[1:]), int(l[1:]), int(x[1:]), int(n[1:])
+
+
+def both_params(qt, q, l, x, n):
+    return capi.make_params(qt, q, l, x, n), ob.make_params(qt, q, l, x, n)
+
+
+def pad_rows(seq, qual, offsets, stride):
+    """ragged -> fixed stride (+ lengths)"""
+    n = len(offsets) - 1
+    lens = np.diff(offsets).astype(np.uint32)
+    qs = np.zeros((n, stride), dtype=np.uint8)
+    ss = np.zeros((n, stride), dtype=np.uint8)
+    for i in range(n):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        qs[i, :b - a] = qual[a:b]
+        ss[i, :b - a] = seq[a:b]
+    return ss.reshape(-1), qs.reshape(-1), lens
+
+
+def test_kernel_selection():
+    q = np.zeros(4096, dtype=np.uint8)  # numpy data is 16/64-byte aligned
+    assert q.ctypes.data % 16 == 0
+    b = capi.Batch(q.ctypes.data, None, None, 152, 150, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 1
+    b = capi.Batch(q.ctypes.data, None, None, 150, 150, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 2
+    off = np.zeros(2, dtype=np.uint64)
+    b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 0, 0, None, 1)
+    assert capi.lib().sk_kernel_for(b) == 2
+
+
+@pytest.mark.parametrize("layout", ["tile", "wave_ragged", "wave_stride"])
+def test_golden_edge_set(sk_ctx, layout):
+    """Every golden grid point of the edge-case reads (lengths 1..31, 99-101, 149-151, 250, 301)."""
+    inp = np.load(os.path.join(GOLD, "edge_inputs.npz"))
+    seq, qual, offsets = inp["seq"], inp["qual"], inp["offsets"]
+    cuts = np.load(os.path.join(GOLD, "cuts_edge.npz"))
+    stride = 304 if layout == "tile" else 301
+    ss, qs, lens = pad_rows(seq, qual, offsets, stride)
+    for k in cuts.files:
+        p, _ = both_params(*parse_key(k))
+        if layout == "wave_ragged":
+            got = sk_ctx.trim_batch(p, qual, seq, offsets=offsets)
+        else:
+            got = sk_ctx.trim_batch(p, qs, ss, stride=stride, lengths=lens)
+        want = cuts[k].astype(np.int32)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (layout, k, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+
+
+@pytest.mark.parametrize("layout", ["tile", "wave_ragged"])
+def test_golden_bundled_file(sk_ctx, layout):
+    """The reference's own test/test.fastq over the golden flag grid."""
+    from fastq_util import parse_fastq, pack_records
+    recs = parse_fastq(open(os.path.join(GOLD, "inputs", "test.fastq"), "rb").read())
+    seq, qual, offsets = pack_records(recs)
+    cuts = np.load(os.path.join(GOLD, "cuts_bundled.npz"))
+    ss, qs, lens = pad_rows(seq, qual, offsets, 152)
+    assert (lens == 150).all()
+    for k in cuts.files:
+        p, _ = both_params(*parse_key(k))
+        if layout == "tile":
+            got = sk_ctx.trim_batch(p, qs, ss, stride=152, read_len=150, n_reads=len(recs))  # uniform variant
+        else:
+            got = sk_ctx.trim_batch(p, qual, seq, offsets=offsets)
+        assert (got == cuts[k].astype(np.int32)).all(), (layout, k)
+
+
+@pytest.mark.parametrize("qt,trunc_n", [("sanger", False), ("sanger", True), ("illumina", True)])
+def test_synthetic_fixed_vs_oracle(sk_ctx, qt, trunc_n):
+    """The bench workload's shape (150 bp, stride 152) at a size the oracle does in a second."""
+    n = 200_003  # not a multiple of 64: exercises the partial last tile
+    seq, qual = synth.make_reads(77, n, 150, qt, lower_n_frac=0.01 if trunc_n else 0.0)
+    qs, ss = synth.pack_fixed(qual, 152), synth.pack_fixed(seq, 152)
+    for q, l, x in ((20, 20, 0), (30, 50, 1), (2, 0, 0)):
+        p, po = both_params(qt, q, l, x, trunc_n)
+        want, err = ob.oracle_trim_batch(po, qs, ss, stride=152, read_len=150, n_reads=n, threads=8)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qs, ss, stride=152, read_len=150, n_reads=n)
+        assert (got == want).all(), (qt, q, l, x, np.nonzero((got != want).any(axis=1))[0][:5])
+        # the general kernel on the unpadded layout must agree too
+        got2 = sk_ctx.trim_batch(p, qual.reshape(-1), seq.reshape(-1), stride=150, read_len=150, n_reads=n)
+        assert (got2 == want).all()
+
+
+def test_synthetic_ragged_vs_oracle(sk_ctx):
+    seq, qual, offsets = synth.make_ragged_reads(5, 50_000, 75, 301, "illumina")
+    for q, l, x, n in ((20, 20, 0, 1), (25, 75, 0, 0), (20, 20, 1, 1)):
+        p, po = both_params("illumina", q, l, x, n)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offsets, threads=8)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offsets)
+        assert (got == want).all()
+        ss, qs, lens = pad_rows(seq, qual, offsets, 304)
+        got = sk_ctx.trim_batch(p, qs, ss, stride=304, lengths=lens)
+        assert (got == want).all()
+
+
+def test_random_fuzz_all_layouts(sk_ctx):
+    """Adversarial quality patterns, all encodings, thresholds 0..45, lengths 1..320."""
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        qt = ["sanger", "solexa", "illumina"][trial % 3]
+        lo, hi = {"sanger": (33, 74), "solexa": (58, 105), "illumina": (64, 105)}[qt]
+        n = 3000
+        lens = rng.integers(1, 321, size=n).astype(np.uint32)
+        if trial % 5 == 0:
+            lens[:] = rng.integers(1, 40)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        tot = int(offs[-1])
+        mode = trial % 4
+        if mode == 0:
+            qual = rng.integers(lo, hi, size=tot)
+        elif mode == 1:
+            qual = np.where(rng.random(tot) < 0.5, lo, hi - 1)
+        elif mode == 2:
+            qual = np.clip(rng.normal((lo + hi) / 2 + rng.integers(-10, 10), 8, tot).astype(int), lo, hi - 1)
+        else:
+            off = {"sanger": 33, "solexa": 64, "illumina": 64}[qt]
+            qual = np.clip(off + rng.integers(0, 45) + rng.integers(-3, 4, size=tot), lo, hi - 1)
+        qual = qual.astype(np.uint8)
+        seq = rng.choice(np.frombuffer(b"ACGTACGTACGTACGTNn" if trial % 2 else b"ACGT" * 50 + b"N", dtype=np.uint8), size=tot)
+        args = (qt, int(rng.integers(0, 45)), int(rng.integers(0, 120)) if trial % 3 else 20, trial % 2, (trial // 2) % 2)
+        p, po = both_params(*args)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=4)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offs)
+        assert (got == want).all(), ("ragged", trial, args)
+        ss, qs, l32 = pad_rows(seq, qual, offs, 320)
+        got = sk_ctx.trim_batch(p, qs, ss, stride=320, lengths=l32)
+        assert (got == want).all(), ("tile", trial, args, np.nonzero((got != want).any(axis=1))[0][:5])
+
+
+def test_range_errors_match_reference(sk_ctx):
+    """errors.json: for each case the device either returns the reference's cut or reports the
+    same (position, char) the reference printed before exit(1)."""
+    cases = json.load(open(os.path.join(GOLD, "errors.json")))
+    for c in cases:
+        pd = c["params"]
+        p = capi.make_params(pd["qualtype"], pd["q"], pd["l"], pd["no5"], pd["trunc_n"])
+        po = ob.make_params(pd["qualtype"], pd["q"], pd["l"], pd["no5"], pd["trunc_n"])
+        qual = np.frombuffer(bytes.fromhex(c["qual_hex"]), dtype=np.uint8)
+        seq = np.frombuffer(c["seq"].encode("latin-1"), dtype=np.uint8)
+        L = len(qual)
+        for layout in ("tile", "wave"):
+            # put the read in the middle of a batch of clean reads
+            stride = 152 if layout == "tile" else 150
+            n = 130
+            qs = np.full((n, stride), qual[0] if c["rc"] == 0 else 75, dtype=np.uint8)
+            qs[:] = 75  # 'K': legal in all three encodings
+            ss = np.full((n, stride), ord("A"), dtype=np.uint8)
+            lens = np.full(n, 150, dtype=np.uint32)
+            qs[70, :L] = qual
+            ss[70, :L] = seq
+            lens[70] = L
+            try:
+                got = sk_ctx.trim_batch(p, qs.reshape(-1), ss.reshape(-1), stride=stride, lengths=lens)
+                assert c["rc"] == 0, (c["desc"], layout, "device missed the error")
+                assert list(got[70]) == c["cut"], (c["desc"], layout, got[70])
+            except capi.RangeError as e:
+                assert c["rc"] == 1, (c["desc"], layout, "device raised a spurious error")
+                assert e.read == 70
+                text = ob.oracle_format_error(po, c["name"].encode("latin-1"), qual.tobytes(), (e.read, e.pos, e.ch))
+                assert text.decode("latin-1") == c["stderr"], (c["desc"], layout)
+
+
+def test_error_reports_lowest_read(sk_ctx):
+    n = 5000
+    qs = np.full((n, 152), 75, dtype=np.uint8)
+    qs[4000, 10] = 10
+    qs[1234, 100] = 200
+    qs[1234, 120] = 7
+    qs[3000, 0] = 0
+    p = capi.make_params("sanger")
+    with pytest.raises(capi.RangeError) as ei:
+        sk_ctx.trim_batch(p, qs.reshape(-1), stride=152, read_len=150, n_reads=n)
+    assert (ei.value.read, ei.value.pos, ei.value.ch) == (1234, 100, 200 - 256)
+
+
+def test_empty_and_tiny_batches(sk_ctx):
+    p = capi.make_params("sanger")
+    assert sk_ctx.trim_batch(p, np.zeros(0, dtype=np.uint8), stride=152, read_len=150, n_reads=0).shape == (0, 2)
+    for n in (1, 63, 64, 65, 255, 257):
+        seq, qual = synth.make_reads(n, n, 150)
+        want, _ = ob.oracle_trim_batch(ob.make_params("sanger"), synth.pack_fixed(qual, 152), stride=152, read_len=150, n_reads=n)
+        got = sk_ctx.trim_batch(p, synth.pack_fixed(qual, 152), stride=152, read_len=150, n_reads=n)
+        assert (got == want).all()
+
+
+def test_async_slots_overlap(sk_ctx):
+    """sk_submit / sk_wait with two slots in flight give the same cuts as the synchronous call."""
+    p, po = both_params("sanger", 20, 20, 0, 0)
+    batches = []
+    for i in range(4):
+        _, qual = synth.make_reads(100 + i, 40_000, 150)
+        qs = synth.pack_fixed(qual, 152)
+        batches.append((qs, np.zeros((40_000, 2), dtype=np.int32)))
+    for i, (qs, out) in enumerate(batches):
+        if i >= 2:
+            sk_ctx.wait(i % 2)
+        sk_ctx.submit(i % 2, p, qs, out, stride=152, read_len=150, n_reads=40_000)
+    sk_ctx.wait(0)
+    sk_ctx.wait(1)
+    for qs, out in batches:
+        want, _ = ob.oracle_trim_batch(po, qs, stride=152, read_len=150, n_reads=40_000, threads=4)
+        assert (out == want).all()
