@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json: reads/s (+ Gbases/s) trimmed, 150 bp SE
+Sanger, q=20 l=20, on N MI355X, with the quality bytes already resident in HBM.
+
+A step = one pass of the scan (sk_scan_device_async, include/sickle_amd.h) over this rank's
+whole batch of synthetic reads.  Weak scaling: every GPU holds --reads reads (default 10 M,
+BASELINE config[1]); reads are independent, so ranks exchange nothing in the timed region and
+only sum their kept/discarded counters afterwards.
+
+Launch: `python bench.py` (N=1) or
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def synth_quals_device(torch, n, length, stride, seed, device, chunk=1 << 20):
+    """The quality model of sickle_amd/synth.py, generated on the GPU: (n, stride) uint8."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.zeros((n, stride), dtype=torch.uint8, device=device)
+    pos = torch.arange(length, device=device, dtype=torch.float32)[None, :]
+    for a in range(0, n, chunk):
+        m = min(chunk, n - a)
+        base = 30.0 + 10.0 * torch.rand((m, 1), generator=g, device=device)
+        decay = 0.25 * torch.rand((m, 1), generator=g, device=device)
+        q = base - decay * pos + 4.0 * torch.randn((m, length), generator=g, device=device)
+        q = q.round_().clamp_(2, 41)
+        head = torch.randint(0, 8, (m, 1), generator=g, device=device)
+        q = torch.where(pos < head, torch.full_like(q, 2.0), q)
+        isn = torch.rand((m, length), generator=g, device=device) < 0.002  # 0.2 % N bases: quality 2
+        q = torch.where(isn, torch.full_like(q, 2.0), q)
+        out[a:a + m, :length] = (q + 33.0).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(qual_host, n, stride, length, threads):
+    """The CPU path timed beside the GPU: the reference's own sliding_window (oracle/_ref, kind
+    "reference") when that prebuilt library travelled with the repo, else the oracle port."""
+    import oracle_bind as ob
+    p = ob.make_params("sanger", 20, 20)
+    if ob.have_ref():
+        kind = "reference"
+        run = lambda th, m: ob.ref_trim_batch(p, qual_host[:m * stride], stride=stride, read_len=length, n_reads=m, threads=th)
+    else:
+        kind = "port"
+        run = lambda th, m: ob.oracle_trim_batch(p, qual_host[:m * stride], stride=stride, read_len=length, n_reads=m, threads=th)[0]
+    run(threads, min(n, 200_000))  # warm the pages
+    m1 = min(n, 2_000_000)
+    t0 = time.perf_counter()
+    run(1, m1)
+    t1 = time.perf_counter() - t0
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cuts = run(threads, n)
+    tn = (time.perf_counter() - t0) / reps
+    return {"value": n / tn, "unit": "reads/s", "cores": threads, "kind": kind,
+            "sample": "%d x %d reads of the same batch on %d threads (%.1f s wall); 1 thread: %.0f reads/s on %d reads"
+                      % (reps, n, threads, tn * reps, m1 / t1, m1),
+            "value_1thread": m1 / t1}, cuts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--len", type=int, default=150)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from sickle_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the scan has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    n, length = args.reads, args.len
+    stride = (length + 7) // 8 * 8
+    qual = synth_quals_device(torch, n, length, stride, 1234 + rank, device)
+    out = torch.empty((n, 2), dtype=torch.int32, device=device)
+    ctx = capi.Context(device=local_rank, slots=1)
+    params = capi.make_params("sanger", 20, 20)
+    # A dedicated (non-default) stream: the C ABI takes the hipStream_t the kernel is launched on,
+    # and the HIP events below are recorded on that same stream.
+    stream = torch.cuda.Stream(device)
+    torch.cuda.synchronize(device)  # the synthetic batch is complete before anything is launched
+
+    def step():
+        ctx.scan_device_async(params, qual.data_ptr(), out.data_ptr(), n, stride=stride, read_len=length,
+                              stream=stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.scan_device_finish(stream.cuda_stream)  # raises on a range error
+
+    # per-launch kernel durations: HIP events on the launch stream
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.scan_device_finish(stream.cuda_stream)
+    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    kept = int((out[:, 1] >= 0).sum().item())
+    bases_kept = int((out[:, 1] - out[:, 0]).clamp_(min=0).sum().item())
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    counts = torch.tensor([kept, n - kept, bases_kept], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts)  # the only exchange: kept / discarded counters, outside the timed region
+    elapsed = float(tmax.item())
+
+    res = None
+    if rank == 0:
+        total_reads = world * n * args.steps
+        algo_bytes = (length + 8) * n  # L quality bytes read + one 8-byte cut pair written, per read
+        achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "reads/sec trimmed (+ Gbases/sec), 150 bp SE Sanger q20 l20, inputs resident in HBM",
+            "value": total_reads / elapsed, "unit": "reads/s",
+            "gbases_per_s": total_reads * length / elapsed / 1e9,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "sickle se, %d synthetic %d bp Sanger reads per GPU, q=20 l=20 (BASELINE configs[1])" % (n, length),
+                       "reads_per_gpu": n, "read_len": length, "stride": stride,
+                       "kernel": capi.lib().sk_kernel_name(1).decode(), "sharding": "reads split across ranks, no collective"},
+            "kept": int(counts[0].item()), "discarded": int(counts[1].item()),
+            "mean_bases_kept": float(counts[2].item()) / max(1, int(counts[0].item())),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1],
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            qh = qual.cpu().numpy().reshape(-1)
+            base, cuts = cpu_baseline(qh, n, stride, length, threads)
+            res["cpu_baseline"] = base
+            # and the checker: the GPU cuts of the whole batch against the CPU path's
+            res["parity_vs_cpu_baseline"] = bool((out.cpu().numpy() == cuts).all())
+            res["speedup_vs_cpu_baseline"] = res["value"] / base["value"]
+            if not res["parity_vs_cpu_baseline"]:
+                print(json.dumps(res))
+                raise SystemExit("GPU cuts differ from the CPU baseline's")
+        print(json.dumps(res))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
