@@ -54,7 +54,7 @@ enum {
     SK_EBUSY = -4   /* slot still in flight */
 };
 
-#define SK_TILE_MAX_STRIDE 640u /* 4 waves x 64 reads x 640 B = the 160 KiB LDS of one CU */
+#define SK_TILE_MAX_STRIDE 512u /* two LDS buffers of 64 reads per wave must fit the 160 KiB of a CU */
 #define SK_MAX_READ_LEN (1u << 24)
 
 /* the config ints of Abstract_Trimmer, reference src/trim.h:16-20 */

@@ -58,6 +58,13 @@ __device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t c4)
     return (y - 0x01010101u) & ~y & H4;
 }
 
+// the first n bytes of x (n <= 0: none, n >= 4: all), the others taken from `filler`
+__device__ __forceinline__ uint32_t first_bytes(uint32_t x, int n, uint32_t filler)
+{
+    const uint32_t keep = n >= 4 ? ~0u : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
+    return (x & keep) | (filler & ~keep);
+}
+
 // flags of bytes [n, 4) cleared, n in 0..4
 __device__ __forceinline__ uint32_t keep_first(uint32_t flags, int n)
 {
@@ -107,9 +114,48 @@ __device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, ui
 } // namespace
 
 // ------------------------------------------------------------------------------------------
-// Tiled kernel: lane per read.
-// LDS per wave: 64*stride bytes of tile + SK_TILE_SLACK bytes the lead stream may over-read.
+// Tiled kernel: lane per read, software-pipelined.
+//
+// Each wave owns two LDS buffers.  While it scans tile t out of one buffer the LDS-DMA of
+// its next tile is already in flight into the other, so HBM latency is hidden inside the
+// wave instead of relying on other waves being out of phase (measured: without this the
+// whole chip convoys -- every wave loads, then every wave computes -- at ~half the rate).
+// The DMA of a tile is retired with a COUNTED s_waitcnt vmcnt(n): n = the vector-memory
+// operations issued after it (the next tile's pieces and the cut store), which are allowed
+// to stay outstanding.  With -n the sequence tile of the same reads rides the same two
+// buffers: Q(t) -> buf0, S(t) -> buf1, Q(t+1) -> buf0, ...
 // ------------------------------------------------------------------------------------------
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// s_waitcnt takes an immediate; n is wave-uniform and small (pieces of one tile + 1)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+    switch (n) {
+#define SK_CASE(N) case N: wait_vmcnt_imm<N>(); break;
+        SK_CASE(0) SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7)
+        SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15)
+        SK_CASE(16) SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22) SK_CASE(23)
+        SK_CASE(24) SK_CASE(25) SK_CASE(26) SK_CASE(27) SK_CASE(28) SK_CASE(29) SK_CASE(30) SK_CASE(31)
+        SK_CASE(32) SK_CASE(33) SK_CASE(34)
+#undef SK_CASE
+    default: wait_vmcnt_imm<0>(); break;
+    }
+}
+
+// number of vector-memory instructions tile_to_lds issues for `bytes`
+__device__ __forceinline__ int tile_pieces(uint32_t bytes)
+{
+    return (int)(((bytes >> 4) + 63) >> 6) + (((bytes & 15u) >> 2) ? 1 : 0);
+}
+
+} // namespace
+
 template <bool UNIFORM, bool HAS_SEQ>
 __global__ void __launch_bounds__(SK_TILE_THREADS)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
@@ -119,32 +165,69 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
     const uint32_t stride = a.stride;
-    const uint32_t wave_lds = 64u * stride + SK_TILE_SLACK;
-    uint8_t *tile = lds + (size_t)wave * wave_lds;
-    const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
+    const uint32_t buf_bytes = 64u * stride + SK_TILE_SLACK;
+    uint8_t *buf0 = lds + (size_t)wave * 2u * buf_bytes;
+    uint8_t *buf1 = buf0 + buf_bytes;
 
     const uint64_t n_tiles = (a.n_reads + 63) >> 6;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * SK_TILE_WAVES + wave;
-    const uint64_t wave_count = (uint64_t)gridDim.x * SK_TILE_WAVES;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t wave_count = (uint64_t)gridDim.x * waves_per_block;
 
-    const uint32_t min4 = splat((uint32_t)a.qmin), hi4 = splat((uint32_t)(127 - a.qmax));
+    const uint32_t min4 = splat((uint32_t)a.qmin), max4 = splat((uint32_t)a.qmax);
+    const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));
     const uint32_t cthr4 = splat((uint32_t)a.cthr);
+    const int range = a.qmax - a.qmin;
 
-    for (uint64_t t = wave_global; t < n_tiles; t += wave_count) {
+    auto tile_bytes_of = [&](uint64_t t) -> uint32_t {
+        return (uint32_t)min((uint64_t)64, a.n_reads - (t << 6)) * stride;
+    };
+
+    uint64_t t = wave_global;
+    if (t >= n_tiles) return;
+
+    // prologue: Q(t) [and S(t)] in flight
+    uint32_t cur_bytes = tile_bytes_of(t);
+    tile_to_lds(qual + (t << 6) * stride, buf0, cur_bytes, lane);
+    if (HAS_SEQ) tile_to_lds(seq + (t << 6) * stride, buf1, cur_bytes, lane);
+    int len_next = 0;
+    if (!UNIFORM) {
+        const uint64_t r = (t << 6) + lane;
+        len_next = r < a.n_reads ? (int)min(lengths[r], stride) : 0;
+    }
+    int parity = 0; // !HAS_SEQ: which buffer holds Q(t)
+
+    for (; t < n_tiles; t += wave_count) {
         const uint64_t r0 = t << 6;
         const uint64_t r = r0 + lane;
-        const uint32_t rows = (uint32_t)min((uint64_t)64, a.n_reads - r0);
-        const uint32_t tile_bytes = rows * stride;
-
-        // the previous trip's LDS reads are complete (their results were consumed), so the
-        // buffer can be refilled; the fill is ordered before this trip's reads by vmcnt(0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tile_to_lds(qual + r0 * stride, tile, tile_bytes, lane);
+        const uint64_t tn = t + wave_count;
+        const bool more = tn < n_tiles;
+        const uint32_t next_bytes = more ? tile_bytes_of(tn) : 0u;
+        const int next_pieces = more ? tile_pieces(next_bytes) : 0;
+        const uint8_t *tile;
 
         const bool active = r < a.n_reads;
         int L = 0;
-        if (active) L = UNIFORM ? (int)a.read_len : (int)min(lengths[r], stride);
+        if (active) L = UNIFORM ? (int)a.read_len : len_next;
+        if (!UNIFORM && more) { // next tile's lengths: an ordinary load, issued ahead of the DMA
+            const uint64_t rn = (tn << 6) + lane;
+            len_next = rn < a.n_reads ? (int)min(lengths[rn], stride) : 0;
+        }
+
+        if (HAS_SEQ) {
+            tile = buf0;
+            // outstanding, oldest first: Q(t), S(t) [, store(t-1) before them]
+            wait_vmcnt(tile_pieces(cur_bytes));
+        } else {
+            tile = parity ? buf1 : buf0;
+            uint8_t *other = parity ? buf0 : buf1;
+            if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
+            wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
+            parity ^= 1;
+        }
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
+
         // reference trim.cpp:21 -- shorter than -l: discarded before any quality is read
         const bool scanned = active && L > 0 && L >= a.lthr;
         if (!scanned) L = 0;
@@ -156,19 +239,38 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         const int wmax = UNIFORM ? (Lmax / 10 ? Lmax / 10 : Lmax) : wave_max(w);
         const int nwinmax = UNIFORM ? Lmax - wmax + 1 : wave_max(nwin);
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        // ---- range check over the whole read (decided against the touched prefix below)
-        uint32_t bad = 0;
-        for (int k = 0; 4 * k < Lmax; ++k) bad |= keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
+        // ---- range check of the whole read in 2 ops per dword: for a char c in [min,max],
+        // |c-min| + |c-max| == max-min, and it is larger for every other byte value, so the
+        // read is clean iff the two SADs add up to L*(max-min).  (Whether a bad char counts is
+        // decided below against the part of the read the reference would have touched.)
+        uint32_t sad = 0;
+        {
+            int k = 0;
+            if (UNIFORM) {
+                for (; 4 * (k + 1) <= Lmax; ++k) {
+                    const uint32_t x = row[k];
+                    sad = __builtin_amdgcn_sad_u8(x, min4, sad);
+                    sad = __builtin_amdgcn_sad_u8(x, max4, sad);
+                }
+            }
+            for (; 4 * k < Lmax; ++k) { // per-lane masking: the last dword (UNIFORM) / mixed lengths
+                const uint32_t x = first_bytes(row[k], L - 4 * k, min4);
+                sad = __builtin_amdgcn_sad_u8(x, min4, sad);
+                sad = __builtin_amdgcn_sad_u8(x, max4, sad);
+            }
+            // every dword visited contributes 4*range when clean (fillers are legal chars)
+            sad -= (uint32_t)(4 * k * range);
+        }
+        const bool bad = scanned && sad != 0;
 
         // ---- S_0 - T : trim.cpp:31-33
         uint32_t acc = 0;
-        for (int k = 0; 4 * k < wmax; ++k) {
-            int nb = w - 4 * k;
-            uint32_t x = row[k];
-            x = nb >= 4 ? x : (nb <= 0 ? 0u : x & ((1u << (8 * nb)) - 1u));
-            acc = __builtin_amdgcn_sad_u8(x, 0u, acc);
+        {
+            int k = 0;
+            if (UNIFORM) {
+                for (; 4 * (k + 1) <= wmax; ++k) acc = __builtin_amdgcn_sad_u8(row[k], 0u, acc);
+            }
+            for (; 4 * k < wmax; ++k) acc = __builtin_amdgcn_sad_u8(first_bytes(row[k], w - 4 * k, 0u), 0u, acc);
         }
         int v = (int)acc - a.craw * w; // sign bit <=> window average below the threshold
 
@@ -182,19 +284,20 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             const int dw0 = base >> 2;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t y = row[dw0 + k];             // chars leaving the window
+                const uint32_t y = row[dw0 + k]; // chars leaving the window
                 const uint32_t lead_hi = row[dw0 + k + m + 1];
                 const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, (uint32_t)sh); // chars entering
                 lead_lo = lead_hi;
-                const uint32_t d = ((x | H4) - y) ^ H4; // per byte: x - y as int8 (both < 128)
+                const int d = (int)(((x | H4) - y) ^ H4); // per byte: x - y as int8 (both < 128)
+                const int t1 = __builtin_amdgcn_sdot4(d, 0x00000001, v, false);
+                const int t2 = __builtin_amdgcn_sdot4(d, 0x00000101, v, false);
+                const int t3 = __builtin_amdgcn_sdot4(d, 0x00010101, v, false);
+                const int t4 = __builtin_amdgcn_sdot4(d, 0x01010101, v, false);
                 M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                v = __builtin_amdgcn_sdot4((int)d, 0x00000001, v, false);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                v = __builtin_amdgcn_sdot4((int)d, 0x00000100, v, false);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                v = __builtin_amdgcn_sdot4((int)d, 0x00010000, v, false);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                v = __builtin_amdgcn_sdot4((int)d, 0x01000000, v, false);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
+                M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
+                v = t4;
             }
             // bit (31 - s) of M: window base+s is below the threshold
             const int nv = nwin - base;
@@ -236,27 +339,28 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         }
 
         // ---- range error: only if the first bad char is one the reference would have read
-        if (__builtin_amdgcn_ballot_w64(bad != 0)) {
-            if (bad != 0) {
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+            if (bad) {
                 const int touched = done ? i1 + w : L;
-                int p = 0;
+                int p = INF;
                 for (int k = 0; 4 * k < L; ++k) {
                     uint32_t f = keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
                     if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
                 }
-                if (p < touched)
-                    report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * stride + p]));
+                if (p < touched) report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * stride + p]));
             }
         }
 
         // ---- the N rule: trim.cpp:86-98 (lowercase n: cut before it; only uppercase N: cut = -2)
         if (HAS_SEQ) {
+            // buf0 is free now: start Q(t+1), then retire S(t)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tile_to_lds(seq + r0 * stride, tile, tile_bytes, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+            wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
+            const uint32_t *srow = reinterpret_cast<const uint32_t *>(buf1 + (size_t)lane * stride);
             int ni = INF, Ni = INF;
             for (int k = 0; 4 * k < Lmax; ++k) {
-                const uint32_t x = row[k];
+                const uint32_t x = srow[k];
                 const uint32_t fn = keep_first(eq_flags(x, splat('n')), L - 4 * k);
                 const uint32_t fN = keep_first(eq_flags(x, splat('N')), L - 4 * k);
                 if (fn && ni == INF) ni = 4 * k + (__builtin_ctz(fn) >> 3);
@@ -264,6 +368,8 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             }
             if (ni != INF) three = ni - 1;
             else if (Ni != INF) three = -2;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane); // S(t+1)
         }
 
         // ---- trim.cpp:103-108
@@ -272,6 +378,10 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             three = -1;
         }
         if (active) out[r] = sk_cut_dev{five, three};
+        // this trip's LDS reads are complete (their results were consumed) before the next
+        // trip may overwrite the buffer they came from
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cur_bytes = next_bytes;
     }
 }
 
@@ -389,13 +499,16 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream)
 {
-    const uint32_t wave_lds = 64u * a->stride + SK_TILE_SLACK;
-    const uint32_t lds_bytes = SK_TILE_WAVES * wave_lds;
-    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
-    const uint64_t blocks_needed = (n_tiles + SK_TILE_WAVES - 1) / SK_TILE_WAVES;
+    // two buffers per wave; as many waves per block (<= 4) and blocks per CU as the 160 KiB allow
+    const uint32_t wave_lds = 2u * (64u * a->stride + SK_TILE_SLACK);
+    int waves = (int)(SK_LDS_PER_CU / wave_lds);
+    if (waves < 1) return hipErrorInvalidValue;
+    if (waves > SK_TILE_WAVES) waves = SK_TILE_WAVES;
+    const uint32_t lds_bytes = (uint32_t)waves * wave_lds;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    if (per_cu < 1) return hipErrorInvalidValue;
     if (per_cu > 8) per_cu = 8;
+    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
+    const uint64_t blocks_needed = (n_tiles + waves - 1) / waves;
     uint64_t grid = (uint64_t)cu_count * per_cu;
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid == 0) return hipSuccess;
@@ -405,8 +518,8 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_TILE_THREADS), lds_bytes, stream, qual, seq, lengths,
-                           out, errword, *a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64u * waves), lds_bytes, stream, qual, seq, lengths, out,
+                           errword, *a);
         return hipGetLastError();
     };
     if (uniform) return has_seq ? launch(sk_scan_tile_kernel<true, true>) : launch(sk_scan_tile_kernel<true, false>);
