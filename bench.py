@@ -139,12 +139,9 @@ def main():
 
     kept = int((out[:, 1] >= 0).sum().item())
     bases_kept = int((out[:, 1] - out[:, 0]).clamp_(min=0).sum().item())
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    counts = torch.tensor([kept, n - kept, bases_kept], dtype=torch.int64, device=device)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts)  # the only exchange: kept / discarded counters, outside the timed region
-    elapsed = float(tmax.item())
+    # the only exchange: kept / discarded counters and the max elapsed, outside the timed region
+    from sickle_amd.shard import reduce_counters
+    counts, elapsed = reduce_counters(dist, [kept, n - kept, bases_kept], elapsed, device)
 
     res = None
     if rank == 0:
@@ -161,8 +158,8 @@ def main():
             "config": {"workload": "sickle se, %d synthetic %d bp Sanger reads per GPU, q=20 l=20 (BASELINE configs[1])" % (n, length),
                        "reads_per_gpu": n, "read_len": length, "stride": stride,
                        "kernel": capi.lib().sk_kernel_name(1).decode(), "sharding": "reads split across ranks, no collective"},
-            "kept": int(counts[0].item()), "discarded": int(counts[1].item()),
-            "mean_bases_kept": float(counts[2].item()) / max(1, int(counts[0].item())),
+            "kept": counts[0], "discarded": counts[1],
+            "mean_bases_kept": counts[2] / max(1, counts[0]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1],

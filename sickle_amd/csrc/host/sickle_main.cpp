@@ -1,0 +1,52 @@
+// sickle_main.cpp -- `sickle {se,pe,--help,--version}`: the dispatch of reference src/sickle.cpp:40-86.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "sickle.h"
+#include "trim_paired.h"
+#include "trim_single.h"
+
+static void main_usage(int status)
+{
+    // text of reference src/sickle.cpp:26-38 (on stdout there too)
+    fprintf(stdout, "\nUsage: %s <command> [options]\n\
+\n\
+Command:\n\
+pe\tpaired-end sequence trimming\n\
+se\tsingle-end sequence trimming\n\
+\n\
+--help, display this help and exit\n\
+--version, output version information and exit\n\n", PROGRAM_NAME);
+    exit(status);
+}
+
+int main(int argc, char *argv[])
+{
+    int retval = 0;
+    if (argc < 2 || (strcmp(argv[1], "pe") != 0 && strcmp(argv[1], "se") != 0 &&
+                     strcmp(argv[1], "--version") != 0 && strcmp(argv[1], "--help") != 0)) {
+        main_usage(EXIT_FAILURE);
+    }
+    if (strcmp(argv[1], "--version") == 0) {
+        // reference src/sickle.cpp:52-54: the line continuations inside that string literal put
+        // two tabs and one tab into the text; kept, since this is what `sickle --version` prints
+        fprintf(stdout, "%s version %0.2f\nCopyright (c) 2011 The Regents of University of California, \
+		Davis Campus.\n%s is free software and comes with ABSOLUTELY NO WARRANTY.\nDistributed under the\
+		 MIT License.\n\nWritten by %s\n", PROGRAM_NAME, VERSION, PROGRAM_NAME, AUTHORS);
+        exit(EXIT_SUCCESS);
+    } else if (strcmp(argv[1], "--help") == 0) {
+        main_usage(EXIT_SUCCESS);
+    } else if (strcmp(argv[1], "pe") == 0) {
+        Trim_Paired trimmer;
+        retval = trimmer.parse_args(argc, argv);
+        if (retval != 0) return retval;
+        retval = trimmer.trim_main();
+    } else {
+        Trim_Single trimmer;
+        retval = trimmer.parse_args(argc, argv);
+        if (retval != 0) return retval;
+        retval = trimmer.trim_main();
+    }
+    return retval;
+}

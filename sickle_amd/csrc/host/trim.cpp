@@ -1,0 +1,241 @@
+#include "trim.h"
+
+#include <sys/stat.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+void error(const char *content)
+{
+    std::cerr << "[ERROR] " << content << std::endl;
+    std::flush(std::cerr);
+}
+void error(const std::string &content) { error(content.c_str()); }
+
+void msg(const char *content)
+{
+    static const bool on = [] {
+        const char *e = getenv("SICKLE_DEBUG_CHATTER");
+        return e && *e && *e != '0';
+    }();
+    if (on) std::cout << "[DEBUGGING] " << content << std::endl;
+}
+void msg(const std::string &content) { msg(content.c_str()); }
+
+// ---------------------------------------------------------------- OutFile
+bool OutFile::open(const char *path, bool gzip)
+{
+    if (gzip) {
+        gz = gzopen(path, "w");
+        if (gz) gzbuffer(gz, 1u << 20);
+        return gz != nullptr;
+    }
+    fp = fopen(path, "w");
+    if (fp) setvbuf(fp, nullptr, _IOFBF, 4u << 20);
+    return fp != nullptr;
+}
+
+void OutFile::write(const std::string &data)
+{
+    if (data.empty()) return;
+    if (fp) {
+        fwrite(data.data(), 1, data.size(), fp);
+    } else if (gz) {
+        // The reference hands the text to gzprintf as the FORMAT string (src/trim_single.cpp:418),
+        // which mangles any '%' (= Sanger Q4).  This writes the bytes themselves.
+        size_t done = 0;
+        while (done < data.size()) {
+            const unsigned n = (unsigned)std::min<size_t>(data.size() - done, 1u << 30);
+            if (gzwrite(gz, data.data() + done, n) <= 0) break;
+            done += n;
+        }
+    }
+}
+
+void OutFile::close()
+{
+    if (fp) fclose(fp);
+    if (gz) gzclose(gz);
+    fp = nullptr;
+    gz = nullptr;
+}
+
+// ---------------------------------------------------------------- Abstract_Trimmer
+Abstract_Trimmer::Abstract_Trimmer()
+    : qualtype(-1), length_threshold(20), qual_threshold(20), no_fiveprime(0), trunc_n(0), debug(0), threads(1),
+      batch_len(1024 * 1024 * DEFAULT_BATCH_LEN), input(nullptr), outfn(nullptr), infn(nullptr), quiet(0),
+      gzip_output(0), kept(0), discard(0), total(0)
+{
+}
+
+Abstract_Trimmer::~Abstract_Trimmer() { close_device(); }
+
+int Abstract_Trimmer::open_device()
+{
+    if (ctx) return 0;
+    int device = 0;
+    if (const char *e = getenv("SICKLE_DEVICE")) device = atoi(e);
+    const int rc = sk_create(device, kSlots, &ctx);
+    if (rc != SK_OK) {
+        // no CPU fallback: the scan exists only as HIP kernels for gfx950
+        fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
+                device, rc);
+        ctx = nullptr;
+        return EXIT_FAILURE;
+    }
+    return 0;
+}
+
+void Abstract_Trimmer::close_device()
+{
+    if (!ctx) return;
+    for (Slot &s : slots) {
+        sk_host_free(ctx, s.qual);
+        sk_host_free(ctx, s.seq);
+        sk_host_free(ctx, s.offsets);
+        sk_host_free(ctx, s.cuts);
+        s = Slot();
+    }
+    sk_destroy(ctx);
+    ctx = nullptr;
+}
+
+void Abstract_Trimmer::grow(Slot &s, size_t bytes, size_t reads, bool need_seq)
+{
+    auto fail = [&](const char *what) {
+        fprintf(stderr, "****Error: could not allocate pinned %s buffer: %s\n\n", what, sk_last_error(ctx));
+        exit(EXIT_FAILURE);
+    };
+    if (bytes + 64 > s.cap_bytes || (need_seq && !s.seq)) {
+        const size_t cap = std::max(s.cap_bytes, bytes + 64 + (bytes >> 3));
+        sk_host_free(ctx, s.qual);
+        sk_host_free(ctx, s.seq);
+        s.seq = nullptr;
+        s.qual = (uint8_t *)sk_host_alloc(ctx, cap);
+        if (!s.qual) fail("quality");
+        if (need_seq) {
+            s.seq = (uint8_t *)sk_host_alloc(ctx, cap);
+            if (!s.seq) fail("sequence");
+        }
+        s.cap_bytes = cap;
+    }
+    if (reads + 1 > s.cap_reads) {
+        const size_t cap = reads + 1 + (reads >> 3);
+        sk_host_free(ctx, s.offsets);
+        sk_host_free(ctx, s.cuts);
+        s.offsets = (uint64_t *)sk_host_alloc(ctx, cap * sizeof(uint64_t));
+        s.cuts = (sk_cut *)sk_host_alloc(ctx, cap * sizeof(sk_cut));
+        if (!s.offsets || !s.cuts) fail("index");
+        s.cap_reads = cap;
+    }
+}
+
+void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
+{
+    Slot &s = slots[slot];
+    const size_t n = reads.size();
+    // Layout: equal-length batches (the usual case) go at a fixed stride that is a multiple of 8
+    // and take the tiled kernel; mixed lengths are packed back to back with an offsets array so
+    // that PCIe carries no padding.
+    size_t total_len = 0;
+    bool uniform = true;
+    const size_t len0 = n ? reads[0].qual.length() : 0;
+    for (const FQEntry &r : reads) {
+        total_len += r.qual.length();
+        uniform = uniform && r.qual.length() == len0;
+    }
+    uniform = uniform && len0 > 0 && ((len0 + 7) / 8 * 8) <= SK_TILE_MAX_STRIDE;
+    const size_t stride = uniform ? (len0 + 7) / 8 * 8 : 0;
+    const size_t bytes = uniform ? n * stride : total_len;
+    const bool need_seq = trunc_n != 0;
+    grow(s, bytes, n, need_seq);
+
+    sk_batch b;
+    memset(&b, 0, sizeof b);
+    if (uniform) {
+        for (size_t i = 0; i < n; ++i) {
+            memcpy(s.qual + i * stride, reads[i].qual.data(), len0);
+            if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), len0);
+        }
+        b.stride = (uint32_t)stride;
+        b.read_len = (uint32_t)len0;
+    } else {
+        size_t at = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t l = reads[i].qual.length();
+            s.offsets[i] = at;
+            memcpy(s.qual + at, reads[i].qual.data(), l);
+            if (need_seq) memcpy(s.seq + at, reads[i].seq.data(), l);
+            at += l;
+        }
+        s.offsets[n] = at;
+        b.offsets = s.offsets;
+    }
+    b.qual = s.qual;
+    b.seq = need_seq ? s.seq : nullptr;
+    b.n_reads = n;
+    sk_params p = {qualtype, qual_threshold, length_threshold, no_fiveprime, trunc_n};
+    const int rc = sk_submit(ctx, slot, &p, &b, s.cuts);
+    if (rc != SK_OK) {
+        fprintf(stderr, "****Error: device scan could not be started (%d): %s\n\n", rc, sk_last_error(ctx));
+        exit(EXIT_FAILURE);
+    }
+}
+
+const cutsites *Abstract_Trimmer::wait_scan(int slot, const std::vector<FQEntry> &reads)
+{
+    static_assert(sizeof(cutsites) == sizeof(sk_cut), "cutsites must match the C ABI's sk_cut");
+    sk_err e;
+    const int rc = sk_wait(ctx, slot, &e);
+    if (rc == SK_ERANGE) {
+        // reference src/trim.cpp:130-136
+        const FQEntry &r = reads[e.read];
+        const int32_t *k = sk_quality_constants(qualtype);
+        const char *tn = sk_typename(qualtype);
+        fprintf(stderr, "ERROR: Quality value (%d) does not fall within correct range for %s encoding.\n", e.ch, tn);
+        fprintf(stderr, "Range for %s encoding: %d-%d\n", tn, k[1], k[2]);
+        fprintf(stderr, "FastQ record: %s\n", std::string(r.name).c_str());
+        fprintf(stderr, "Quality string: %s\n", std::string(r.qual).c_str());
+        fprintf(stderr, "Quality char: '%c'\n", (char)e.ch);
+        fprintf(stderr, "Quality position: %d\n", (int)e.pos + 1);
+        exit(1);
+    }
+    if (rc != SK_OK) {
+        fprintf(stderr, "****Error: device scan failed (%d): %s\n\n", rc, sk_last_error(ctx));
+        exit(EXIT_FAILURE);
+    }
+    return reinterpret_cast<const cutsites *>(slots[slot].cuts);
+}
+
+void Abstract_Trimmer::append_record(std::string &out, const FQEntry &read, const cutsites &cs)
+{
+    const size_t five = (size_t)cs.five_prime_cut;
+    const size_t n = (size_t)(cs.three_prime_cut - cs.five_prime_cut);
+    out.append(read.name.data(), read.name.size());
+    out.push_back('\n');
+    out.append(read.seq.data() + five, n);
+    out.push_back('\n');
+    out.append(read.comment.data(), read.comment.size());
+    out.push_back('\n');
+    out.append(read.qual.data() + five, n);
+    out.push_back('\n');
+}
+
+// reference src/trim_single.cpp:194-211 / src/trim_paired.cpp:246-263 (the caller halves max for PE)
+int Abstract_Trimmer::recommended_batch_len_for(const char *path, unsigned long long max_len) const
+{
+    struct stat st;
+    if (stat(path, &st) != 0) {
+        // the reference dies here with an uncaught std::filesystem error (abort)
+        fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path);
+        exit(EXIT_FAILURE);
+    }
+    const unsigned long long min_len = 20;
+    const unsigned long long recommended = (unsigned long long)st.st_size / 8;
+    unsigned long long chosen = recommended;
+    if (recommended < min_len) chosen = min_len;
+    else if (recommended > max_len) chosen = max_len;
+    msg(std::string("Batch size is ") + std::to_string(chosen / (1024 * 1024)) + std::string("MB"));
+    return (int)chosen;
+}

@@ -1,0 +1,130 @@
+// trim.h -- Abstract_Trimmer: the base of the two mode drivers.
+//
+// Role of reference src/trim.{h,cpp}.  In the reference this class IS the hot path
+// (sliding_window / get_quality_num run on CPU threads).  Here the scan runs on the GPU behind
+// the C ABI of include/sickle_amd.h, and this class holds what both drivers share around it:
+// the configuration ints (same names as reference src/trim.h:16-30), the device session with
+// its pinned staging slots, batch packing, record emission and the range-error exit.
+#ifndef SICKLE_TRIM_H
+#define SICKLE_TRIM_H
+
+#include <zlib.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "FQEntry.h"
+#include "GZReader.h"
+#include "sickle.h"
+#include "sickle_amd.h"
+
+// plain or gzip output file (reference: std::ofstream / gzFile pairs, src/trim.h:24-25)
+class OutFile {
+public:
+    bool open(const char *path, bool gzip);
+    void write(const std::string &data);
+    void close();
+    bool is_open() const { return fp || gz; }
+
+private:
+    FILE *fp = nullptr;
+    gzFile gz = nullptr;
+};
+
+// bounded hand-off between pipeline stages
+template <typename T> class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void push(T v)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool pop(T &out) // false once closed and drained
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        not_empty_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable not_empty_, not_full_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+class Abstract_Trimmer {
+public:
+    virtual int parse_args(int argc, char *argv[]) = 0;
+    virtual int trim_main() = 0;
+    virtual void usage(int status, char const *msg) = 0;
+    virtual ~Abstract_Trimmer();
+
+protected:
+    Abstract_Trimmer();
+
+    // ---- the scan of one batch of reads on the device (what processing_thread did on CPU threads)
+    static const int kSlots = 2;
+    int open_device(); // 0 ok; prints and returns EXIT_FAILURE without a usable gfx950 device
+    void close_device();
+    // packs the quality (and, with -n, sequence) bytes of `reads` into the slot's pinned buffers
+    // and enqueues H2D + scan + D2H; returns at once
+    void submit_scan(int slot, const std::vector<FQEntry> &reads);
+    // blocks until the slot is done; on an out-of-range quality prints the reference's message
+    // (src/trim.cpp:130-135) and exits 1.  The cut array stays valid until the slot is reused.
+    const cutsites *wait_scan(int slot, const std::vector<FQEntry> &reads);
+
+    // name\n seq[five,three)\n comment\n qual[five,three)\n  (src/trim_single.cpp:393-396)
+    static void append_record(std::string &out, const FQEntry &read, const cutsites &cs);
+
+    int recommended_batch_len_for(const char *path, unsigned long long max_len) const;
+
+    // reference src/trim.h:16-30
+    int qualtype;
+    int length_threshold;
+    int qual_threshold;
+    int no_fiveprime;
+    int trunc_n;
+    int debug;
+    int threads, batch_len;
+    GZReader *input;
+    char *outfn;
+    char *infn;
+    int quiet;
+    int gzip_output;
+    int kept;
+    int discard;
+    int total;
+
+private:
+    struct Slot {
+        uint8_t *qual = nullptr, *seq = nullptr;
+        size_t cap_bytes = 0;
+        uint64_t *offsets = nullptr;
+        sk_cut *cuts = nullptr;
+        size_t cap_reads = 0;
+    };
+    sk_ctx *ctx = nullptr;
+    Slot slots[kSlots];
+    void grow(Slot &s, size_t bytes, size_t reads, bool need_seq);
+};
+
+#endif

@@ -1,0 +1,404 @@
+#include "trim_paired.h"
+
+#include <getopt.h>
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+// reference src/trim_paired.cpp:16-36
+static struct option paired_long_options[] = {
+    {"qual-type", required_argument, 0, 't'},
+    {"pe-file1", required_argument, 0, 'f'},
+    {"pe-file2", required_argument, 0, 'r'},
+    {"pe-interleaved", required_argument, 0, 'c'},
+    {"output-pe1", required_argument, 0, 'o'},
+    {"output-pe2", required_argument, 0, 'p'},
+    {"output-single", required_argument, 0, 's'},
+    {"output-interleaved", required_argument, 0, 'm'},
+    {"qual-threshold", required_argument, 0, 'q'},
+    {"length-threshold", required_argument, 0, 'l'},
+    {"no-fiveprime", no_argument, 0, 'x'},
+    {"truncate-n", no_argument, 0, 'n'},
+    {"gzip-output", no_argument, 0, 'g'},
+    {"quiet", no_argument, 0, 'z'},
+    {"threads", no_argument, 0, 'a'},
+    {"batch", no_argument, 0, 'b'},
+    {"help", no_argument, NULL, CHAR_MIN - 2},
+    {"version", no_argument, NULL, CHAR_MIN - 3},
+    {NULL, 0, NULL, 0}};
+
+// text of reference src/trim_paired.cpp:38-76
+void Trim_Paired::usage(int status, char const *msg)
+{
+    fprintf(stderr, "\nIf you have separate files for forward and reverse reads:\n");
+    fprintf(stderr, "Usage: %s pe [options] -f <paired-end forward fastq file> -r <paired-end reverse fastq file> -t <quality type> -o <trimmed PE forward file> -p <trimmed PE reverse file> -s <trimmed singles file>\n\n", PROGRAM_NAME);
+    fprintf(stderr, "If you have one file with interleaved forward and reverse reads:\n");
+    fprintf(stderr, "Usage: %s pe [options] -c <interleaved input file> -t <quality type> -m <interleaved trimmed paired-end output> -s <trimmed singles file>\n\n\
+If you have one file with interleaved reads as input and you want ONLY one interleaved file as output:\n\
+Usage: %s pe [options] -c <interleaved input file> -t <quality type> -m <interleaved trimmed output>\n\n", PROGRAM_NAME, PROGRAM_NAME);
+    fprintf(stderr, "Options:\n\
+Paired-end separated reads\n\
+--------------------------\n\
+-f, --pe-file1, Input paired-end forward fastq file (Input files must have same number of records)\n\
+-r, --pe-file2, Input paired-end reverse fastq file\n\
+-o, --output-pe1, Output trimmed forward fastq file\n\
+-p, --output-pe2, Output trimmed reverse fastq file. Must use -s option.\n\n\
+Paired-end interleaved reads\n\
+----------------------------\n");
+    fprintf(stderr, "-c, --pe-interleaved, Combined (interleaved) input paired-end fastq\n\
+-m, --output-interleaved, Output combined (interleaved) paired-end fastq file. Must use -s option.\n\
+--------------\n\
+-t, --qual-type, Type of quality values (solexa (CASAVA < 1.3), illumina (CASAVA 1.3 to 1.7), sanger (which is CASAVA >= 1.8)) (required)\n");
+    fprintf(stderr, "-s, --output-single, Output trimmed singles fastq file\n\
+-q, --qual-threshold, Threshold for trimming based on average quality in a window. Default 20.\n\
+-l, --length-threshold, Threshold to keep a read based on length after trimming. Default 20.\n\
+-x, --no-fiveprime, Don't do five prime trimming.\n\
+-n, --truncate-n, Truncate sequences at position of first N.\n\
+-a, --threads, Number of threads to use. Default and minimum: Available cores - 1.\n\
+-b, --batch, maximum MB of data to read from the input file at each cycle.\n\
+\tThe greater the value, the greater the memory usage can be. The value, multiplied by 1024^2, must be \n\
+\tbigger than the lenght of the longest read. Minimum 1. Default: 512.\n");
+
+    fprintf(stderr, "-g, --gzip-output, Output gzipped files.\n--quiet, do not output trimming info\n\
+--help, display this help and exit\n\
+--version, output version information and exit\n\n");
+
+    if (msg) fprintf(stderr, "%s\n\n", msg);
+    exit(status);
+}
+
+Trim_Paired::Trim_Paired()
+    : input2(nullptr), input_inter(nullptr), interleaved_s(0), outfn2(nullptr), outfnc(nullptr), sfn(nullptr),
+      infn2(nullptr), infnc(nullptr), kept_p(0), discard_p(0), kept_s1(0), kept_s2(0), discard_s1(0), discard_s2(0)
+{
+    threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    batch_len = 1024 * 1024 * DEFAULT_BATCH_LEN;
+}
+
+static void print_version_and_exit()
+{
+    fprintf(stdout,
+            "%s version %0.3f\nCopyright (c) 2011 The Regents "
+            "of University of California, Davis Campus.\n"
+            "%s is free software and comes with ABSOLUTELY NO WARRANTY.\n"
+            "Distributed under the MIT License.\n\nWritten by %s\n",
+            PROGRAM_NAME, VERSION, PROGRAM_NAME, AUTHORS);
+    exit(EXIT_SUCCESS);
+}
+
+int Trim_Paired::parse_args(int argc, char *argv[])
+{
+    int optc;
+    while (1) {
+        int option_index = 0;
+        // "M:" is accepted by the optstring but has no case: -M falls to usage (exit 1), as in the reference
+        optc = getopt_long(argc, argv, "df:r:c:t:o:p:m:M:s:q:a:b:l:xng", paired_long_options, &option_index);
+        if (optc == -1) break;
+        switch (optc) {
+        case 'f': infn = strdup(optarg); break;
+        case 'r': infn2 = strdup(optarg); break;
+        case 'c': infnc = strdup(optarg); break;
+        case 't':
+            if (!strcmp(optarg, "illumina")) qualtype = ILLUMINA;
+            else if (!strcmp(optarg, "solexa")) qualtype = SOLEXA;
+            else if (!strcmp(optarg, "sanger")) qualtype = SANGER;
+            else {
+                fprintf(stderr, "Error: Quality type '%s' is not a valid type.\n", optarg);
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'o': outfn = strdup(optarg); break;
+        case 'p': outfn2 = strdup(optarg); break;
+        case 'm':
+            outfnc = strdup(optarg);
+            interleaved_s = 1;
+            break;
+        case 's': sfn = strdup(optarg); break;
+        case 'q':
+            qual_threshold = atoi(optarg);
+            if (qual_threshold < 0) {
+                fprintf(stderr, "Quality threshold must be >= 0\n");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'l':
+            length_threshold = atoi(optarg);
+            if (length_threshold < 0) {
+                fprintf(stderr, "Length threshold must be >= 0\n");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'x': no_fiveprime = 1; break;
+        case 'n': trunc_n = 1; break;
+        case 'g': gzip_output = 1; break;
+        case 'z': quiet = 1; break;
+        case 'd': debug = 1; break;
+        case 'a':
+            if (!optarg) usage(EXIT_FAILURE, NULL); // long form has no argument: the reference crashes here
+            threads = atoi(optarg);
+            break;
+        case 'b':
+            if (!optarg) usage(EXIT_FAILURE, NULL);
+            batch_len = 1024 * 1024 * (atoi(optarg));
+            break;
+        case CHAR_MIN - 2: usage(EXIT_SUCCESS, NULL); break;
+        case CHAR_MIN - 3: print_version_and_exit(); break;
+        case '?':
+        default: usage(EXIT_FAILURE, NULL); break;
+        }
+    }
+
+    if (qualtype == -1) {
+        usage(EXIT_FAILURE, "****Error: Quality type is required.");
+        return EXIT_FAILURE;
+    }
+    if (!infn && !infnc) {
+        usage(EXIT_FAILURE, "****Error: Must have either -f OR -c argument.");
+        return EXIT_FAILURE;
+    }
+    if (threads < 1) threads = 1;
+    if (infnc) batch_len = recommended_batch_len(infnc, batch_len);
+    else if (infn) batch_len = recommended_batch_len(infn, batch_len);
+    return 0;
+}
+
+int Trim_Paired::recommended_batch_len(const char *path, int max_batch_len)
+{
+    return recommended_batch_len_for(path, (unsigned)max_batch_len / 2); // src/trim_paired.cpp:248
+}
+
+// reference src/trim_paired.cpp:626-731
+int Trim_Paired::init_streams()
+{
+    const bool gz = gzip_output != 0;
+    if (infnc) { /* interleaved input */
+        if (infn || infn2 || outfn || outfn2) {
+            usage(EXIT_FAILURE, "****Error: Cannot have -f, -r, -o, or -p options with -c.");
+            return EXIT_FAILURE;
+        }
+        if (!outfnc) {
+            // the reference opens a NULL file name here and dies; -m is required with -c
+            usage(EXIT_FAILURE, "****Error: Using the -c option means you must have the -m option.");
+            return EXIT_FAILURE;
+        }
+        input_inter = new GZReader(infnc, batch_len, true);
+        if (!input_inter->is_open()) return EXIT_FAILURE;
+        input = input_inter;
+        if (!outfile_interleaved.open(outfnc, gz)) {
+            fprintf(stderr, "****Error: Could not open interleaved output file '%s'.\n\n", outfnc);
+            return EXIT_FAILURE;
+        }
+    } else { /* forward and reverse input files */
+        if (infn && (!infn2 || !outfn || !outfn2 || !sfn)) {
+            usage(EXIT_FAILURE, "****Error: Using the -f option means you must have the -r, -o, -p, and -s options.");
+            return EXIT_FAILURE;
+        }
+        if (infn && (infnc || interleaved_s)) {
+            usage(EXIT_FAILURE, "****Error: The -f option cannot be used in combination with -c, -m, or -M.");
+            return EXIT_FAILURE;
+        }
+        input = new GZReader(infn, batch_len);
+        if (!input->is_open()) return EXIT_FAILURE;
+        input2 = new GZReader(infn2, batch_len);
+        if (!input2->is_open()) return EXIT_FAILURE;
+        if (!outfile.open(outfn, gz)) {
+            fprintf(stderr, "****Error: Could not open output file '%s'.\n\n", outfn);
+            return EXIT_FAILURE;
+        }
+        if (!outfile2.open(outfn2, gz)) {
+            fprintf(stderr, "****Error: Could not open output file '%s'.\n\n", outfn2);
+            return EXIT_FAILURE;
+        }
+    }
+    if (sfn) {
+        if (!outfile_single.open(sfn, gz)) {
+            fprintf(stderr, "****Error: Could not open single output file '%s'.\n\n", sfn);
+            return EXIT_FAILURE;
+        }
+    }
+    return open_device();
+}
+
+void Trim_Paired::close_streams()
+{
+    if (input_inter) {
+        delete input_inter;
+    } else {
+        delete input;
+        delete input2;
+    }
+    input = input2 = input_inter = nullptr;
+    outfile_single.close();
+    outfile.close();
+    outfile2.close();
+    outfile_interleaved.close();
+    close_device();
+}
+
+// Pair classification and the three output streams of one ingest batch: reference
+// src/trim_paired.cpp:515-624.  Pair k of the batch sits in queue k mod T and the queues are
+// written one after the other (:388-403, :530-533), so -a T > 1 gives queue-major file order.
+void Trim_Paired::output_paired(Work &w)
+{
+    int b_kept_p = 0, b_kept_s1 = 0, b_kept_s2 = 0, b_discard_p = 0, b_discard_s1 = 0, b_discard_s2 = 0;
+    std::string fq1, fq2, singles;
+    const size_t pairs = w.reads.size() / 2;
+    const size_t T = (size_t)threads;
+    for (size_t q = 0; q < T; ++q) {
+        for (size_t k = q; k < pairs; k += T) {
+            const FQEntry &read1 = w.reads[2 * k], &read2 = w.reads[2 * k + 1];
+            const cutsites &cs1 = w.cuts[2 * k], &cs2 = w.cuts[2 * k + 1];
+            const bool r1 = cs1.three_prime_cut >= 0; // src/trim_paired.cpp:500,502
+            const bool r2 = cs2.three_prime_cut >= 0;
+            if (r1 && r2) {
+                append_record(fq1, read1, cs1);
+                if (input_inter) append_record(fq1, read2, cs2);
+                else append_record(fq2, read2, cs2);
+                b_kept_p += 2;
+            } else if (r1 || r2) {
+                if (r1) {
+                    append_record(singles, read1, cs1);
+                    b_kept_s1++;
+                    b_discard_s2++;
+                } else {
+                    append_record(singles, read2, cs2);
+                    b_kept_s2++;
+                    b_discard_s1++;
+                }
+            } else {
+                b_discard_p += 2;
+            }
+        }
+    }
+    kept_p += b_kept_p;
+    kept_s1 += b_kept_s1;
+    kept_s2 += b_kept_s2;
+    discard_p += b_discard_p;
+    discard_s1 += b_discard_s1;
+    discard_s2 += b_discard_s2;
+    // src/trim_paired.cpp:593 computes `total` from the PER-BATCH locals that shadow the members,
+    // so the summary's "Total input FastQ records" is the size of the last batch written.
+    total = b_kept_p + b_kept_s1 + b_kept_s2 + b_discard_p + b_discard_s1 + b_discard_s2;
+
+    if (input_inter) {
+        outfile_interleaved.write(fq1);
+        if (sfn) outfile_single.write(singles);
+    } else {
+        outfile.write(fq1);
+        outfile2.write(fq2);
+        if (sfn) outfile_single.write(singles);
+    }
+    delete w.batch;
+    delete w.batch2;
+    w.batch = w.batch2 = nullptr;
+}
+
+int Trim_Paired::trim_main()
+{
+    total = 0;
+    kept_p = discard_p = kept_s1 = kept_s2 = discard_s1 = discard_s2 = 0;
+    int res = init_streams();
+    if (res != 0) return res;
+
+    Channel<Work *> parsed(2), scanned(2);
+    std::thread reader([&] {
+        // the batch loop of reference src/trim_paired.cpp:280-453, minus the worker threads
+        while (true) {
+            Batch *batch = input->get_batch_buffering_lines();
+            if (batch == NULL) break;
+            Batch *batch2 = NULL;
+            if (!input_inter) {
+                batch2 = input2->get_batch_buffering_lines();
+                if (batch2 == NULL) {
+                    delete batch;
+                    break;
+                }
+                if (batch2->n_lines() != batch->n_lines()) {
+                    error("Batch2 and Batch1 have different lengths, exiting"); // :335-338
+                    delete batch;
+                    delete batch2;
+                    break;
+                }
+            }
+            Work *w = new Work();
+            w->batch = batch;
+            w->batch2 = batch2;
+            w->reads.reserve((size_t)batch->n_lines() / (input_inter ? 4 : 2));
+            int chars_read_from_batch = 0;
+            int last_read_position = 0, last_read_position2 = 0; // per batch in PE (:309-310)
+            while (batch->has_lines()) {
+                if (chars_read_from_batch > batch_len) break; // :352-358
+                w->reads.emplace_back(last_read_position, batch);
+                last_read_position = w->reads.back().position;
+                const int read_len = (int)w->reads.back().seq.length();
+                if (input_inter && !batch->has_lines()) {
+                    error("Reading interleaved pair: read1 loaded, but no read2 to load. Maybe it's not an interleaved file?");
+                    exit(EXIT_FAILURE);
+                }
+                if (input_inter) {
+                    w->reads.emplace_back(last_read_position, batch);
+                    last_read_position = w->reads.back().position;
+                } else {
+                    w->reads.emplace_back(last_read_position2, batch2);
+                    last_read_position2 = w->reads.back().position;
+                }
+                chars_read_from_batch += read_len;
+            }
+            if (chars_read_from_batch == 0) { // :407-409
+                delete batch;
+                delete batch2;
+                delete w;
+                break;
+            }
+            parsed.push(w);
+        }
+        parsed.close();
+    });
+    std::thread writer([&] {
+        Work *w;
+        while (scanned.pop(w)) {
+            output_paired(*w);
+            delete w;
+        }
+    });
+
+    Work *inflight[kSlots] = {nullptr, nullptr};
+    auto finish = [&](int slot) {
+        Work *w = inflight[slot];
+        if (!w) return;
+        const cutsites *cs = wait_scan(slot, w->reads);
+        w->cuts.assign(cs, cs + w->reads.size());
+        inflight[slot] = nullptr;
+        scanned.push(w);
+    };
+    int i = 0;
+    Work *w;
+    while (parsed.pop(w)) {
+        const int slot = i % kSlots;
+        finish(slot);
+        submit_scan(slot, w->reads);
+        inflight[slot] = w;
+        ++i;
+    }
+    for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    scanned.close();
+    reader.join();
+    writer.join();
+
+    if (!quiet) { // reference src/trim_paired.cpp:464-476
+        if (infn && infn2) fprintf(stdout, "\nPE forward file: %s\nPE reverse file: %s\n", infn, infn2);
+        if (infnc) fprintf(stdout, "\nPE interleaved file: %s\n", infnc);
+        fprintf(stdout, "\nTotal input FastQ records: %d (%d pairs)\n", total, (total / 2));
+        fprintf(stdout, "\nFastQ paired records kept: %d (%d pairs)\n", kept_p, (kept_p / 2));
+        if (input_inter) fprintf(stdout, "FastQ single records kept: %d\n", (kept_s1 + kept_s2));
+        else fprintf(stdout, "FastQ single records kept: %d (from PE1: %d, from PE2: %d)\n", (kept_s1 + kept_s2), kept_s1, kept_s2);
+        fprintf(stdout, "FastQ paired records discarded: %d (%d pairs)\n", discard_p, (discard_p / 2));
+        if (input_inter) fprintf(stdout, "FastQ single records discarded: %d\n\n", (discard_s1 + discard_s2));
+        else fprintf(stdout, "FastQ single records discarded: %d (from PE1: %d, from PE2: %d)\n\n", (discard_s1 + discard_s2), discard_s1, discard_s2);
+    }
+    close_streams();
+    return EXIT_SUCCESS;
+}

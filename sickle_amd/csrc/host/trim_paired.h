@@ -1,0 +1,38 @@
+// trim_paired.h -- `sickle pe`.  Role of reference src/trim_paired.{h,cpp}: same class name,
+// entry points, options, messages, counters and exit codes.
+#ifndef SICKLE_TRIM_PAIRED_H
+#define SICKLE_TRIM_PAIRED_H
+
+#include "trim.h"
+
+class Trim_Paired : public Abstract_Trimmer {
+public:
+    Trim_Paired();
+    int parse_args(int argc, char *argv[]) override;
+    int trim_main() override;
+    void usage(int status, char const *msg) override;
+    int recommended_batch_len(const char *path, int max_batch_len);
+
+protected:
+    struct Work {
+        Batch *batch = nullptr, *batch2 = nullptr;
+        std::vector<FQEntry> reads; // mate 1 of pair k at 2k, mate 2 at 2k+1 (the reference's scan order)
+        std::vector<cutsites> cuts;
+    };
+    int init_streams();
+    void close_streams();
+    void output_paired(Work &w);
+
+    GZReader *input2;
+    GZReader *input_inter;
+    OutFile outfile, outfile2, outfile_interleaved, outfile_single;
+    int interleaved_s;
+    char *outfn2; /* reverse file out name */
+    char *outfnc; /* interleaved file out name */
+    char *sfn;    /* singles file out name */
+    char *infn2;  /* reverse input filename */
+    char *infnc;  /* interleaved input filename */
+    int kept_p, discard_p, kept_s1, kept_s2, discard_s1, discard_s2;
+};
+
+#endif

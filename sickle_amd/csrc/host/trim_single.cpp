@@ -1,0 +1,256 @@
+#include "trim_single.h"
+
+#include <getopt.h>
+
+#include <climits>
+
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+// reference src/trim_single.cpp:20-35 (--threads/--batch are declared without an argument
+// there too, so only the short forms -a N / -b N carry a value)
+static struct option single_long_options[] = {
+    {"fastq-file", required_argument, 0, 'f'},
+    {"output-file", required_argument, 0, 'o'},
+    {"qual-type", required_argument, 0, 't'},
+    {"qual-threshold", required_argument, 0, 'q'},
+    {"length-threshold", required_argument, 0, 'l'},
+    {"no-fiveprime", no_argument, 0, 'x'},
+    {"discard-n", no_argument, 0, 'n'},
+    {"gzip-output", no_argument, 0, 'g'},
+    {"quiet", no_argument, 0, 'z'},
+    {"threads", no_argument, 0, 'a'},
+    {"batch", no_argument, 0, 'b'},
+    {"help", no_argument, NULL, CHAR_MIN - 2},
+    {"version", no_argument, NULL, CHAR_MIN - 3},
+    {NULL, 0, NULL, 0}};
+
+// text of reference src/trim_single.cpp:37-61
+void Trim_Single::usage(int status, char const *msg)
+{
+    fprintf(stderr, "\nUsage: %s se [options] -f <fastq sequence file> -t <quality type> -o <trimmed fastq file>\n\
+\n\
+Options:\n\
+-f, --fastq-file, Input fastq file (required)\n\
+-t, --qual-type, Type of quality values (solexa (CASAVA < 1.3), illumina (CASAVA 1.3 to 1.7), sanger (which is CASAVA >= 1.8)) (required)\n\
+-o, --output-file, Output trimmed fastq file (required)\n", PROGRAM_NAME);
+
+    fprintf(stderr, "-q, --qual-threshold, Threshold for trimming based on average quality in a window. Default 20.\n\
+-l, --length-threshold, Threshold to keep a read based on length after trimming. Default 20.\n\
+-x, --no-fiveprime, Don't do five prime trimming.\n\
+-n, --trunc-n, Truncate sequences at position of first N.\n\
+-g, --gzip-output, Output gzipped files.\n\
+-a, --threads, Number of threads to use. Default and minimum: Available cores - 1.\n\
+-b, --batch, maximum MB of data to read from the input file at each cycle.\n\
+\tThe greater the value, the greater the memory usage can be. The value, multiplied by 1024^2, must be \n\
+\tbigger than the lenght of the longest read. Minimum 1. Default: 512.\n\
+--quiet, Don't print out any trimming information\n\
+--help, display this help and exit\n\
+--version, output version information and exit\n\n");
+
+    if (msg) fprintf(stderr, "%s\n\n", msg);
+    exit(status);
+}
+
+Trim_Single::Trim_Single()
+{
+    threads = (int)std::thread::hardware_concurrency(); // DEFAULT_THREADS, reference src/sickle.h:23-25
+    if (threads < 1) threads = 1;
+    batch_len = 1024 * 1024 * DEFAULT_BATCH_LEN;
+}
+
+static void print_version_and_exit()
+{
+    // case_GETOPT_VERSION_CHAR, reference src/sickle.h:51-58
+    fprintf(stdout,
+            "%s version %0.3f\nCopyright (c) 2011 The Regents "
+            "of University of California, Davis Campus.\n"
+            "%s is free software and comes with ABSOLUTELY NO WARRANTY.\n"
+            "Distributed under the MIT License.\n\nWritten by %s\n",
+            PROGRAM_NAME, VERSION, PROGRAM_NAME, AUTHORS);
+    exit(EXIT_SUCCESS);
+}
+
+int Trim_Single::parse_args(int argc, char *argv[])
+{
+    int optc;
+    while (1) {
+        int option_index = 0;
+        optc = getopt_long(argc, argv, "df:t:o:q:a:b:l:zxng", single_long_options, &option_index);
+        if (optc == -1) break;
+        switch (optc) {
+        case 'f':
+            infn = strdup(optarg);
+            break;
+        case 't':
+            if (!strcmp(optarg, "illumina")) qualtype = ILLUMINA;
+            else if (!strcmp(optarg, "solexa")) qualtype = SOLEXA;
+            else if (!strcmp(optarg, "sanger")) qualtype = SANGER;
+            else {
+                fprintf(stderr, "Error: Quality type '%s' is not a valid type.\n", optarg);
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'o':
+            outfn = strdup(optarg);
+            break;
+        case 'q':
+            qual_threshold = atoi(optarg);
+            if (qual_threshold < 0) {
+                fprintf(stderr, "Quality threshold must be >= 0\n");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'l':
+            length_threshold = atoi(optarg);
+            if (length_threshold < 0) {
+                fprintf(stderr, "Length threshold must be >= 0\n");
+                return EXIT_FAILURE;
+            }
+            break;
+        case 'x': no_fiveprime = 1; break;
+        case 'n': trunc_n = 1; break;
+        case 'g': gzip_output = 1; break;
+        case 'z': quiet = 1; break;
+        case 'd': debug = 1; break;
+        case 'a':
+            // the long form carries no argument (optarg NULL): the reference crashes in atoi there
+            if (!optarg) usage(EXIT_FAILURE, NULL);
+            threads = atoi(optarg);
+            break;
+        case 'b':
+            if (!optarg) usage(EXIT_FAILURE, NULL);
+            batch_len = 1024 * 1024 * (atoi(optarg));
+            break;
+        case CHAR_MIN - 2: usage(EXIT_SUCCESS, NULL); break;
+        case CHAR_MIN - 3: print_version_and_exit(); break;
+        case '?':
+        default: usage(EXIT_FAILURE, NULL); break;
+        }
+    }
+
+    if (qualtype == -1 || !infn || !outfn)
+        usage(EXIT_FAILURE, "****Error: Must have quality type, input file, and output file.");
+
+    if (!strcmp(infn, outfn)) {
+        fprintf(stderr, "****Error: Input file is same as output file.\n\n");
+        return EXIT_FAILURE;
+    }
+    if (threads < 1) threads = 1; // the reference would spawn no worker and write nothing
+    batch_len = recommended_batch_len(infn, batch_len);
+    return 0;
+}
+
+int Trim_Single::recommended_batch_len(const char *path, int max_batch_len)
+{
+    return recommended_batch_len_for(path, (unsigned)max_batch_len); // src/trim_single.cpp:194-211
+}
+
+int Trim_Single::init_streams()
+{
+    input = new GZReader(infn, batch_len, false);
+    if (!input->is_open()) return EXIT_FAILURE; // message printed by the reader
+    if (!outfile.open(outfn, gzip_output != 0)) {
+        fprintf(stderr, "****Error: Could not open output file '%s'.\n\n", outfn);
+        return EXIT_FAILURE;
+    }
+    return open_device();
+}
+
+void Trim_Single::close_streams()
+{
+    delete input;
+    input = nullptr;
+    outfile.close();
+    close_device();
+}
+
+// One ingest batch -> output text.  The reference deals read k of a batch into queue (k+1) mod T
+// and writes the queues one after the other (src/trim_single.cpp:263-298, :382-405), so with
+// -a T > 1 the records of a batch come out queue-major.  Reproduced, since it is the file order.
+void Trim_Single::output_single(Work &w)
+{
+    std::string to_print;
+    const size_t n = w.reads.size();
+    to_print.reserve((size_t)w.batch->sequences_len + 4 * n);
+    const size_t T = (size_t)threads;
+    for (size_t q = 0; q < T; ++q) {
+        for (size_t k = (q + T - 1) % T; k < n; k += T) {
+            const cutsites &cs = w.cuts[k];
+            if (!(cs.three_prime_cut >= 0)) { // src/trim_single.cpp:368
+                discard++;
+            } else {
+                append_record(to_print, w.reads[k], cs);
+                kept++;
+            }
+        }
+    }
+    total = kept + discard;
+    outfile.write(to_print);
+    delete w.batch;
+    w.batch = nullptr;
+}
+
+int Trim_Single::trim_main()
+{
+    kept = 0;
+    discard = 0;
+    total = 0;
+    int res = init_streams();
+    if (res != 0) return res;
+
+    // ingest thread -> (this thread: device) -> output thread; two batches in flight on the
+    // device so that the H2D copy of one overlaps the scan of the other
+    Channel<Work *> parsed(2), scanned(2);
+    std::thread reader([&] {
+        int last_read_position = 0; // counts across batches in SE (src/trim_single.cpp:238)
+        while (Batch *batch = input->get_batch_buffering_lines()) {
+            Work *w = new Work();
+            w->batch = batch;
+            w->reads.reserve((size_t)batch->n_lines() / 4);
+            while (batch->has_lines()) {
+                w->reads.emplace_back(last_read_position, batch); // validates, exits on a bad record
+                last_read_position = w->reads.back().position;
+            }
+            parsed.push(w);
+        }
+        parsed.close();
+    });
+    std::thread writer([&] {
+        Work *w;
+        while (scanned.pop(w)) {
+            output_single(*w);
+            delete w;
+        }
+    });
+
+    Work *inflight[kSlots] = {nullptr, nullptr};
+    auto finish = [&](int slot) {
+        Work *w = inflight[slot];
+        if (!w) return;
+        const cutsites *cs = wait_scan(slot, w->reads);
+        w->cuts.assign(cs, cs + w->reads.size());
+        inflight[slot] = nullptr;
+        scanned.push(w);
+    };
+    int i = 0;
+    Work *w;
+    while (parsed.pop(w)) {
+        const int slot = i % kSlots;
+        finish(slot);
+        submit_scan(slot, w->reads);
+        inflight[slot] = w;
+        ++i;
+    }
+    for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    scanned.close();
+    reader.join();
+    writer.join();
+
+    if (!quiet)
+        fprintf(stdout, "\nSE input file: %s\n\nTotal FastQ records: %d\nFastQ records kept: %d\nFastQ records discarded: %d\n\n",
+                infn, total, kept, discard);
+    close_streams();
+    return EXIT_SUCCESS;
+}

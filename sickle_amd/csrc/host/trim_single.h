@@ -1,0 +1,28 @@
+// trim_single.h -- `sickle se`.  Role of reference src/trim_single.{h,cpp}: same class name,
+// same entry points (parse_args / trim_main / usage), same options, messages and exit codes.
+#ifndef SICKLE_TRIM_SINGLE_H
+#define SICKLE_TRIM_SINGLE_H
+
+#include "trim.h"
+
+class Trim_Single : public Abstract_Trimmer {
+public:
+    Trim_Single();
+    int parse_args(int argc, char *argv[]) override;
+    int recommended_batch_len(const char *path, int max_len);
+    int trim_main() override;
+    void usage(int status, char const *msg) override;
+    int init_streams();
+    void close_streams();
+
+private:
+    struct Work {
+        Batch *batch = nullptr;
+        std::vector<FQEntry> reads;
+        std::vector<cutsites> cuts;
+    };
+    void output_single(Work &w);
+    OutFile outfile;
+};
+
+#endif

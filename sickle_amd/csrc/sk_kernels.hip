@@ -156,7 +156,9 @@ __device__ __forceinline__ int tile_pieces(uint32_t bytes)
 
 } // namespace
 
-template <bool UNIFORM, bool HAS_SEQ>
+// ABLATE (diagnostic launches of tools/ablate only; the product always runs 0):
+//   1 = DMA + cut store only (no scan), 2 = scan only (tile loaded once, then reused)
+template <bool UNIFORM, bool HAS_SEQ, int ABLATE = 0>
 __global__ void __launch_bounds__(SK_TILE_THREADS)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
@@ -222,11 +224,22 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         } else {
             tile = parity ? buf1 : buf0;
             uint8_t *other = parity ? buf0 : buf1;
-            if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
-            wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
-            parity ^= 1;
+            if (ABLATE == 2) {
+                tile = buf0;
+                wait_vmcnt(0);
+            } else {
+                if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
+                wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
+                parity ^= 1;
+            }
         }
         const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
+        if (ABLATE == 1) {
+            if (active) out[r] = sk_cut_dev{(int)row[0], (int)row[1]};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cur_bytes = next_bytes;
+            continue;
+        }
 
         // reference trim.cpp:21 -- shorter than -l: discarded before any quality is read
         const bool scanned = active && L > 0 && L >= a.lthr;
@@ -499,11 +512,12 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream)
 {
-    // two buffers per wave; as many waves per block (<= 4) and blocks per CU as the 160 KiB allow
+    // Two LDS buffers per wave.  Waves never synchronise with each other, so one wave per
+    // workgroup: up to 8 single-wave workgroups per CU, as the 160 KiB allow (measured 10 %
+    // faster than 2 workgroups of 4 waves at the same LDS footprint).
     const uint32_t wave_lds = 2u * (64u * a->stride + SK_TILE_SLACK);
-    int waves = (int)(SK_LDS_PER_CU / wave_lds);
-    if (waves < 1) return hipErrorInvalidValue;
-    if (waves > SK_TILE_WAVES) waves = SK_TILE_WAVES;
+    if (wave_lds > SK_LDS_PER_CU) return hipErrorInvalidValue;
+    const int waves = 1;
     const uint32_t lds_bytes = (uint32_t)waves * wave_lds;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
     if (per_cu > 8) per_cu = 8;
@@ -524,6 +538,31 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
     };
     if (uniform) return has_seq ? launch(sk_scan_tile_kernel<true, true>) : launch(sk_scan_tile_kernel<true, false>);
     return has_seq ? launch(sk_scan_tile_kernel<false, true>) : launch(sk_scan_tile_kernel<false, false>);
+}
+
+// diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py)
+extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cut_dev *out, unsigned long long *errword,
+                                            const sk_scan_args *a, int cu_count, int waves, int per_cu, hipStream_t stream)
+{
+    const uint32_t wave_lds = 2u * (64u * a->stride + SK_TILE_SLACK);
+    if (waves < 1) waves = SK_TILE_WAVES;
+    const uint32_t lds_bytes = (uint32_t)waves * wave_lds;
+    if (per_cu < 1) per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    const uint64_t blocks_needed = (n_tiles + waves - 1) / waves;
+    if (grid > blocks_needed) grid = blocks_needed;
+    auto launch = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64u * waves), lds_bytes, stream, qual,
+                           (const uint8_t *)nullptr, (const uint32_t *)nullptr, out, errword, *a);
+        return hipGetLastError();
+    };
+    if (mode == 1) return launch(sk_scan_tile_kernel<true, false, 1>);
+    if (mode == 2) return launch(sk_scan_tile_kernel<true, false, 2>);
+    return launch(sk_scan_tile_kernel<true, false, 0>);
 }
 
 extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,

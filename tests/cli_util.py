@@ -1,0 +1,97 @@
+"""Shared by the CLI tests: replays the reference `sickle pe -a 1` runs recorded in
+tests/golden/e2e.json against one of this repo's binaries and compares output md5s."""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+from fastq_util import parse_fastq
+from sickle_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+INPUTS = os.path.join(GOLD, "inputs")
+PRODUCT_BIN = os.path.join(ROOT, "sickle_amd", "sickle")              # HIP: needs the GPU
+HOSTCHECK_BIN = os.path.join(ROOT, "tests", "cpu_shim", "sickle_hostcheck")  # oracle-backed, tests only
+
+
+def build_hostcheck():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpu_shim")], check=True)
+    return HOSTCHECK_BIN
+
+
+def md5_file(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def e2e():
+    return json.load(open(os.path.join(GOLD, "e2e.json")))
+
+
+def prepare_inputs(tmp):
+    """The files make_golden.py wrote next to the reference run (same seeds -> same bytes)."""
+    tmp = str(tmp)
+    s1, q1 = synth.make_reads(101, 3000, 150, "sanger")
+    s2, q2 = synth.make_reads(202, 3000, 150, "sanger")
+    open(os.path.join(tmp, "syn_R1.fastq"), "wb").write(synth.fastq_bytes(s1, q1, suffix="/1"))
+    open(os.path.join(tmp, "syn_R2.fastq"), "wb").write(synth.fastq_bytes(s2, q2, suffix="/2"))
+    sa, qa, oa = synth.make_ragged_reads(303, 2000, 75, 301, "illumina")
+    recs = parse_fastq(synth.fastq_bytes_ragged(sa, qa, oa))
+    inter = b"".join(b"\n".join(r) + b"\n" for r in recs)
+    open(os.path.join(tmp, "syn_mixed_inter.fastq"), "wb").write(inter)
+    with gzip.GzipFile(os.path.join(tmp, "syn_mixed_inter.fastq.gz"), "wb", mtime=0) as f:
+        f.write(inter)
+    shutil.copyfile(os.path.join(INPUTS, "test.fastq"), os.path.join(tmp, "self_copy.fastq"))
+    for name in ("test.f.fastq", "test.r.fastq"):
+        with gzip.GzipFile(os.path.join(tmp, name + ".gz"), "wb", mtime=0) as f:
+            f.write(open(os.path.join(INPUTS, name), "rb").read())
+    want = e2e()["synth_inputs_md5"]
+    for name, m in want.items():
+        assert md5_file(os.path.join(tmp, name)) == m, "synthetic input %s drifted from the golden run" % name
+
+
+def run_cli(binary, tmp, argv, env=None):
+    real = [a.format(tmp=str(tmp), inputs=INPUTS) for a in argv]
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    return subprocess.run([binary] + real, capture_output=True, timeout=600, env=e)
+
+
+def summary_block(stdout_text):
+    """The non-chatter part of stdout: drops the reference's [DEBUGGING] lines and its other
+    progress prints, keeps the summary block (with blank lines)."""
+    keep = []
+    for line in stdout_text.split("\n"):
+        if line.startswith("[DEBUGGING]") or line.startswith("Building reader for") or \
+                line in ("Setting se trimming params", "trim_main()"):
+            continue
+        keep.append(line)
+    return "\n".join(keep).strip("\n")
+
+
+def check_run(binary, tmp, name, rec):
+    """Replays one golden run; returns nothing, asserts."""
+    for o in rec["outputs"]:
+        p = os.path.join(str(tmp), o)
+        if os.path.exists(p):
+            os.remove(p)
+    pr = run_cli(binary, tmp, rec["argv"])
+    assert pr.returncode == rec["rc"], (name, pr.returncode, pr.stderr[-500:])
+    for o, meta in rec["outputs"].items():
+        p = os.path.join(str(tmp), o)
+        assert os.path.exists(p), (name, o)
+        assert os.path.getsize(p) == meta["size"], (name, o, os.path.getsize(p), meta["size"])
+        assert md5_file(p) == meta["md5"], (name, o)
+    want = summary_block(rec["stdout"]).replace(INPUTS, "{inputs}")
+    got = summary_block(pr.stdout.decode("latin-1")).replace(INPUTS, "{inputs}")
+    # the golden run used its own temp dir for {tmp} inputs: compare with paths normalised
+    import re
+    norm = lambda s: re.sub(r"/tmp/tmp[^/\s]+/", "{tmp}/", s.replace(str(tmp) + "/", "{tmp}/"))  # noqa: E731
+    assert norm(got) == norm(want), (name, got, want)

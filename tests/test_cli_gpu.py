@@ -1,0 +1,49 @@
+"""GPU: the PRODUCT binary (sickle_amd/sickle, linked against the HIP library) replays the
+reference runs of tests/golden/e2e.json: byte-identical output files, same summary block."""
+import os
+
+import pytest
+
+import cli_util as cu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli_gpu")
+    cu.prepare_inputs(d)
+    return d
+
+
+def test_product_binary_is_the_hip_build():
+    assert os.path.exists(cu.PRODUCT_BIN), "build sickle_amd/sickle first (__graft_entry__.build())"
+    import subprocess
+    out = subprocess.run(["ldd", cu.PRODUCT_BIN], capture_output=True).stdout.decode()
+    assert "libsickle_amd.so" in out and "libamdhip64" in out
+
+
+@pytest.mark.parametrize("name", sorted(cu.e2e()["runs"].keys()))
+def test_reference_runs_byte_identical_on_gpu(workdir, name):
+    cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name])
+
+
+def test_se_on_gpu_equals_selfpaired_reference(workdir):
+    rec = cu.e2e()["runs"]["se_equiv_selfpair_illumina"]
+    out = os.path.join(str(workdir), "se_self.fastq")
+    pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", "{inputs}/test.fastq", "-t", "illumina", "-o", out, "-a", "1"])
+    assert pr.returncode == 0, pr.stderr
+    assert cu.md5_file(out) == rec["outputs"]["o1.fastq"]["md5"]
+
+
+def test_range_error_exit_on_gpu(workdir):
+    import json
+    from sickle_amd import synth
+    c = [c for c in json.load(open(os.path.join(cu.GOLD, "errors.json"))) if c["rc"] == 1 and len(c["seq"]) == 150][0]
+    seq, qual = synth.make_reads(5, 40, 150, "sanger")
+    bad = c["name"].encode("latin-1") + b"\n" + c["seq"].encode("latin-1") + b"\n+\n" + bytes.fromhex(c["qual_hex"]) + b"\n"
+    path = os.path.join(str(workdir), "bad.fastq")
+    open(path, "wb").write(synth.fastq_bytes(seq[:20], qual[:20]) + bad + synth.fastq_bytes(seq[20:], qual[20:], start=20))
+    pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", path, "-t", c["params"]["qualtype"], "-o", "{tmp}/bad_out.fastq", "-a", "1"])
+    assert pr.returncode == 1
+    assert pr.stderr.decode("latin-1") == c["stderr"]

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: times the uniform tile kernel whole / DMA-only / scan-only at several
+occupancies (waves per block x blocks per CU).  Not part of the product or of bench.py."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+
+class Args(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("stride", C.c_uint32), ("read_len", C.c_uint32), ("qmin", C.c_int32),
+                ("qmax", C.c_int32), ("craw", C.c_int32), ("cthr", C.c_int32), ("cthr_raw", C.c_int32),
+                ("lthr", C.c_int32), ("no5", C.c_int32), ("truncn", C.c_int32)]
+
+lib = C.CDLL(os.path.join(ROOT, "sickle_amd", "libsickle_amd.so"))
+lib.sk_launch_tile_ablate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.c_void_p]
+dev = torch.device("cuda", 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+q = bench.synth_quals_device(torch, n, 150, 152, 1234, dev)
+out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+err = torch.full((1,), -1, dtype=torch.int64, device=dev)
+a = Args(n, 152, 150, 33, 126, 53, 53, 53, 20, 0, 0)
+s = torch.cuda.Stream(dev)
+torch.cuda.synchronize()
+for waves, per_cu in ((4, 2), (4, 1), (2, 4), (1, 8), (2, 2), (1, 4)):
+    for mode in (0, 1, 2):
+        ts = []
+        for it in range(8):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            rc = lib.sk_launch_tile_ablate(mode, q.data_ptr(), out.data_ptr(), err.data_ptr(), C.byref(a), 256, waves, per_cu, s.cuda_stream)
+            e1.record(s)
+            s.synchronize()
+            assert rc == 0, rc
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        ms = ts[len(ts) // 2]
+        print("waves/block %d blocks/CU %d mode %d (%s): %.3f ms  %.0f GB/s algorithmic" %
+              (waves, per_cu, mode, ["full", "dma-only", "scan-only"][mode], ms, 158 * n / ms / 1e6), flush=True)
