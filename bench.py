@@ -44,6 +44,25 @@ def synth_quals_device(torch, n, length, stride, seed, device, chunk=1 << 20):
     return out
 
 
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(qual_host, n, stride, length, threads):
     """The CPU path timed beside the GPU: the reference's own sliding_window (oracle/_ref, kind
     "reference") when that prebuilt library travelled with the repo, else the oracle port."""
@@ -166,7 +185,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            threads = host_cores()
             qh = qual.cpu().numpy().reshape(-1)
             base, cuts = cpu_baseline(qh, n, stride, length, threads)
             res["cpu_baseline"] = base

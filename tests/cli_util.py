@@ -89,9 +89,13 @@ def check_run(binary, tmp, name, rec):
         assert os.path.exists(p), (name, o)
         assert os.path.getsize(p) == meta["size"], (name, o, os.path.getsize(p), meta["size"])
         assert md5_file(p) == meta["md5"], (name, o)
-    want = summary_block(rec["stdout"]).replace(INPUTS, "{inputs}")
-    got = summary_block(pr.stdout.decode("latin-1")).replace(INPUTS, "{inputs}")
-    # the golden run used its own temp dir for {tmp} inputs: compare with paths normalised
+    want = summary_block(rec["stdout"])
+    got = summary_block(pr.stdout.decode("latin-1"))
+    # the golden run had its own repo root and temp dir: compare with paths normalised
     import re
-    norm = lambda s: re.sub(r"/tmp/tmp[^/\s]+/", "{tmp}/", s.replace(str(tmp) + "/", "{tmp}/"))  # noqa: E731
+
+    def norm(s):
+        s = re.sub(r"[^\s]*/tests/golden/inputs", "{inputs}", s.replace(str(tmp) + "/", "{tmp}/"))
+        return re.sub(r"/tmp/tmp[^/\s]+/", "{tmp}/", s)
+
     assert norm(got) == norm(want), (name, got, want)
