@@ -156,14 +156,34 @@ __device__ __forceinline__ int tile_pieces(uint32_t bytes)
 
 } // namespace
 
-// ABLATE (diagnostic launches of tools/ablate only; the product always runs 0):
+typedef int sk_v4i __attribute__((ext_vector_type(4)));
+typedef int sk_v16i __attribute__((ext_vector_type(16)));
+typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
+
+// MFMA = true (uniform-length batches with w <= 33): the window sums are taken off the vector
+// ALU.  A box filter is a banded 0/1 matrix, so for 32 windows x 32 reads
+//     S[window][read] - T = band(w)[window][pos] x Q[pos][read] + (-T)
+// is two v_mfma_i32_32x32x32_i8 (positions 32b..32b+63), exact in int32.  The B operand of a lane
+// is 16 consecutive quality bytes of one read -- two ds_read_b64 from its LDS row, no shuffling;
+// the A operand is a per-lane constant.  The rows of `band` are permuted so that a lane's 16
+// accumulators are 16 CONSECUTIVE windows (lane half h: windows 16h..16h+15), which leaves the
+// vector ALU one v_alignbit per window to collect the sign bits.  The integer matrix pipe is
+// otherwise idle in this kernel; measured, the VALU count per tile falls from ~1000 to ~420 and
+// the kernel goes from issue-bound to DMA-bound.  This is not a GEMM reshaping of the problem:
+// the data stay in their row layout and every byte is still read from HBM exactly once.
+//
+// ABLATE (diagnostic launches of tools/ablate.py only; the product always runs 0):
 //   1 = DMA + cut store only (no scan), 2 = scan only (tile loaded once, then reused)
-template <bool UNIFORM, bool HAS_SEQ, int ABLATE = 0>
-__global__ void __launch_bounds__(SK_TILE_THREADS)
+// __launch_bounds__(.., 2): at >= 2 waves per SIMD the register budget is <= 256, which makes hipcc
+// keep the MFMA accumulators in VGPRs (with AGPR accumulators every sign-bit collect would first
+// need a v_accvgpr_read, and the -T seed a v_accvgpr_write: +48 VALU per 32 windows).
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int ABLATE = 0>
+__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                     unsigned long long *errword, sk_scan_args a)
 {
+    static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -181,6 +201,33 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));
     const uint32_t cthr4 = splat((uint32_t)a.cthr);
     const int range = a.qmax - a.qmin;
+
+    // ---- constants of the matrix path (uniform L => uniform w)
+    sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0};
+    sk_v16i negT;
+    const int half = lane >> 5;
+    if (MFMA) {
+        const int Lu = (int)a.read_len;
+        const int wu = Lu / 10 ? Lu / 10 : Lu;
+        // this lane supplies row m' = lane&31 of A; the hardware puts row m' into accumulator
+        // reg r of lane half hh with m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be
+        // window 16*hh + r
+        const int mp = lane & 31;
+        const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
+        const int win = 16 * hh + r;
+        union { sk_v4i v; int8_t b[16]; } f0, f1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int k = 16 * half + t; // the position (relative to 32*b) this byte multiplies
+            f0.b[t] = (int8_t)((win <= k && k < win + wu) ? 1 : 0);
+            f1.b[t] = (int8_t)((win <= k + 32 && k + 32 < win + wu) ? 1 : 0);
+        }
+        bandA0 = f0.v;
+        bandA1 = f1.v;
+        const int T = a.craw * wu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negT[i] = -T;
+    }
 
     auto tile_bytes_of = [&](uint64_t t) -> uint32_t {
         return (uint32_t)min((uint64_t)64, a.n_reads - (t << 6)) * stride;
@@ -276,43 +323,12 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         }
         const bool bad = scanned && sad != 0;
 
-        // ---- S_0 - T : trim.cpp:31-33
-        uint32_t acc = 0;
-        {
-            int k = 0;
-            if (UNIFORM) {
-                for (; 4 * (k + 1) <= wmax; ++k) acc = __builtin_amdgcn_sad_u8(row[k], 0u, acc);
-            }
-            for (; 4 * k < wmax; ++k) acc = __builtin_amdgcn_sad_u8(first_bytes(row[k], w - 4 * k, 0u), 0u, acc);
-        }
-        int v = (int)acc - a.craw * w; // sign bit <=> window average below the threshold
-
         // ---- all windows, 32 per trip: trim.cpp:34-81 without the breaks
         bool found5 = a.no5 != 0; // with -x the 3' search starts at window 0 (trim.cpp:62)
         bool done = false;
         int i0 = 0, i1 = 0;
-        uint32_t lead_lo = row[m];
-        for (int base = 0; base < nwinmax; base += 32) {
-            uint32_t M = 0;
-            const int dw0 = base >> 2;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t y = row[dw0 + k]; // chars leaving the window
-                const uint32_t lead_hi = row[dw0 + k + m + 1];
-                const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, (uint32_t)sh); // chars entering
-                lead_lo = lead_hi;
-                const int d = (int)(((x | H4) - y) ^ H4); // per byte: x - y as int8 (both < 128)
-                const int t1 = __builtin_amdgcn_sdot4(d, 0x00000001, v, false);
-                const int t2 = __builtin_amdgcn_sdot4(d, 0x00000101, v, false);
-                const int t3 = __builtin_amdgcn_sdot4(d, 0x00010101, v, false);
-                const int t4 = __builtin_amdgcn_sdot4(d, 0x01010101, v, false);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
-                M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
-                v = t4;
-            }
-            // bit (31 - s) of M: window base+s is below the threshold
+        // 32-window state step; bit (31 - s) of M: window base+s is below the threshold
+        auto step32 = [&](uint32_t M, int base) {
             const int nv = nwin - base;
             const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
             uint32_t lt = M & vmask;
@@ -330,6 +346,71 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             if (found5 && !done && lt) { // trim.cpp:61
                 i1 = base + __builtin_clz(lt);
                 done = true;
+            }
+        };
+
+        if (MFMA) {
+            // lane (n = lane&31, half): 16 bytes of read 32g+n at positions 32*kb + 16*half
+            const uint8_t *frag0 = tile + (size_t)(lane & 31) * stride + 16 * half;
+            const uint8_t *frag1 = frag0 + (size_t)32 * stride;
+            auto load_frag = [](const uint8_t *p) -> sk_v4i {
+                const uint64_t lo = *reinterpret_cast<const uint64_t *>(p);
+                const uint64_t hi = *reinterpret_cast<const uint64_t *>(p + 8);
+                sk_v4i f = {(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
+                return f;
+            };
+            sk_v4i q0 = load_frag(frag0), q1 = load_frag(frag1);
+            for (int base = 0; base < nwinmax; base += 32) {
+                const sk_v4i q0n = load_frag(frag0 + base + 32), q1n = load_frag(frag1 + base + 32);
+                sk_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
+                sk_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0n, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1n, d1, 0, 0, 0);
+                q0 = q0n;
+                q1 = q1n;
+                uint32_t p0 = 0, p1 = 0; // 16 sign bits each, window order
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p1 = __builtin_amdgcn_alignbit(p1, (uint32_t)d1[i], 31);
+                // lanes 0..31 keep reads 0..31 (group 0), lanes 32..63 reads 32..63 (group 1):
+                // s[0] = windows 0..15 of the lane's read, s[1] = windows 16..31
+                const sk_v2u s = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
+                step32((s[0] << 16) | s[1], base);
+            }
+        } else {
+            // ---- S_0 - T : trim.cpp:31-33
+            uint32_t acc = 0;
+            {
+                int k = 0;
+                if (UNIFORM) {
+                    for (; 4 * (k + 1) <= wmax; ++k) acc = __builtin_amdgcn_sad_u8(row[k], 0u, acc);
+                }
+                for (; 4 * k < wmax; ++k) acc = __builtin_amdgcn_sad_u8(first_bytes(row[k], w - 4 * k, 0u), 0u, acc);
+            }
+            int v = (int)acc - a.craw * w; // sign bit <=> window average below the threshold
+            uint32_t lead_lo = row[m];
+            for (int base = 0; base < nwinmax; base += 32) {
+                uint32_t M = 0;
+                const int dw0 = base >> 2;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t y = row[dw0 + k]; // chars leaving the window
+                    const uint32_t lead_hi = row[dw0 + k + m + 1];
+                    const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, (uint32_t)sh); // chars entering
+                    lead_lo = lead_hi;
+                    const int d = (int)(((x | H4) - y) ^ H4); // per byte: x - y as int8 (both < 128)
+                    const int t1 = __builtin_amdgcn_sdot4(d, 0x00000001, v, false);
+                    const int t2 = __builtin_amdgcn_sdot4(d, 0x00000101, v, false);
+                    const int t3 = __builtin_amdgcn_sdot4(d, 0x00010101, v, false);
+                    const int t4 = __builtin_amdgcn_sdot4(d, 0x01010101, v, false);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
+                    v = t4;
+                }
+                step32(M, base);
             }
         }
         const bool have5 = found5 && !a.no5;
@@ -528,6 +609,9 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
     if (grid == 0) return hipSuccess;
     const bool uniform = lengths == nullptr;
     const bool has_seq = a->truncn != 0;
+    // the matrix path: one window width for the whole batch, band within two 32-position blocks
+    const uint32_t wu = a->read_len / 10 ? a->read_len / 10 : a->read_len;
+    const bool mfma = uniform && wu <= 33 && a->read_len > 0;
     auto launch = [&](auto kern) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -536,6 +620,7 @@ extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, co
                            errword, *a);
         return hipGetLastError();
     };
+    if (mfma) return has_seq ? launch(sk_scan_tile_kernel<true, true, true>) : launch(sk_scan_tile_kernel<true, false, true>);
     if (uniform) return has_seq ? launch(sk_scan_tile_kernel<true, true>) : launch(sk_scan_tile_kernel<true, false>);
     return has_seq ? launch(sk_scan_tile_kernel<false, true>) : launch(sk_scan_tile_kernel<false, false>);
 }
@@ -560,9 +645,15 @@ extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cu
                            (const uint8_t *)nullptr, (const uint32_t *)nullptr, out, errword, *a);
         return hipGetLastError();
     };
-    if (mode == 1) return launch(sk_scan_tile_kernel<true, false, 1>);
-    if (mode == 2) return launch(sk_scan_tile_kernel<true, false, 2>);
-    return launch(sk_scan_tile_kernel<true, false, 0>);
+    // modes 0..2: matrix path (whole / DMA only / scan only); 10..12: the same on the vector-ALU path
+    switch (mode) {
+    case 0: return launch(sk_scan_tile_kernel<true, false, true, 0>);
+    case 1: return launch(sk_scan_tile_kernel<true, false, true, 1>);
+    case 2: return launch(sk_scan_tile_kernel<true, false, true, 2>);
+    case 10: return launch(sk_scan_tile_kernel<true, false, false, 0>);
+    case 12: return launch(sk_scan_tile_kernel<true, false, false, 2>);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,

@@ -22,8 +22,9 @@ err = torch.full((1,), -1, dtype=torch.int64, device=dev)
 a = Args(n, 152, 150, 33, 126, 53, 53, 53, 20, 0, 0)
 s = torch.cuda.Stream(dev)
 torch.cuda.synchronize()
-for waves, per_cu in ((4, 2), (4, 1), (2, 4), (1, 8), (2, 2), (1, 4)):
-    for mode in (0, 1, 2):
+NAMES = {0: "mfma full", 1: "dma-only", 2: "mfma scan-only", 10: "valu full", 12: "valu scan-only"}
+for waves, per_cu in ((1, 8), (1, 6), (1, 4), (2, 4)):
+    for mode in (0, 1, 2, 10, 12):
         ts = []
         for it in range(8):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,4 +37,4 @@ for waves, per_cu in ((4, 2), (4, 1), (2, 4), (1, 8), (2, 2), (1, 4)):
         ts.sort()
         ms = ts[len(ts) // 2]
         print("waves/block %d blocks/CU %d mode %d (%s): %.3f ms  %.0f GB/s algorithmic" %
-              (waves, per_cu, mode, ["full", "dma-only", "scan-only"][mode], ms, 158 * n / ms / 1e6), flush=True)
+              (waves, per_cu, mode, NAMES[mode], ms, 158 * n / ms / 1e6), flush=True)
