@@ -10,6 +10,7 @@
 #define SK_TILE_SLACK 128u /* bytes a lane may read past its tile (the lead stream runs ahead) */
 #define SK_WAVE_THREADS 256
 #define SK_LDS_PER_CU (160u * 1024u)
+#define SK_TILE_NBUF_DEFAULT 1 /* LDS buffers per wave for the quality tile (see sk_kernels.hip) */
 
 struct sk_cut_dev {
     int32_t five, three;

@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sk_device.h"
 
@@ -95,16 +96,29 @@ __device__ __forceinline__ void report_error(unsigned long long *errword, uint64
 using gptr_t = const __attribute__((address_space(1))) void *;
 using lptr_t = __attribute__((address_space(3))) void *;
 
-// Copies `bytes` (multiple of 4) from global `src` (16-byte aligned) to the wave-private LDS
-// region `dst` with LDS-DMA; the LDS image is byte-identical to the global one.
+// Copies `bytes` (multiple of 4, wave-uniform) from global `src` (16-byte aligned) to the
+// wave-private LDS region `dst` with LDS-DMA; the LDS image is byte-identical to the global one.
+// Full 1 KiB pieces are issued four per trip through the instruction's immediate offset (it
+// moves the global and the LDS address together), without touching EXEC; only the last, partial
+// piece is predicated.
 __device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, uint32_t bytes, int lane)
 {
-    const uint32_t nfull = bytes >> 4;
-    for (uint32_t c0 = 0; c0 < nfull; c0 += 64) { // c0 is wave-uniform: one 1 KiB piece per trip
-        if (c0 + lane < nfull)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(c0 + lane) * 16), (lptr_t)(dst + c0 * 16),
-                                             16, 0, 0);
+    const uint32_t nfull = bytes >> 4;  // 16-byte chunks
+    const uint32_t pieces = nfull >> 6; // full 64-lane pieces
+    const uint8_t *sp = src + (size_t)lane * 16;
+    uint32_t p = 0;
+    for (; p + 4 <= pieces; p += 4) {
+        gptr_t g = (gptr_t)(sp + (size_t)p * 1024);
+        lptr_t l = (lptr_t)(dst + p * 1024);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
     }
+    for (; p < pieces; ++p)
+        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, 0);
+    if ((uint32_t)lane < (nfull & 63u))
+        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, 0);
     const uint32_t tail = (bytes & 15u) >> 2; // 0..3 dwords after the last full 16-byte chunk
     if ((uint32_t)lane < tail)
         __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)nfull * 16 + lane * 4), (lptr_t)(dst + nfull * 16),
@@ -168,30 +182,36 @@ typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 // the A operand is a per-lane constant.  The rows of `band` are permuted so that a lane's 16
 // accumulators are 16 CONSECUTIVE windows (lane half h: windows 16h..16h+15), which leaves the
 // vector ALU one v_alignbit per window to collect the sign bits.  The integer matrix pipe is
-// otherwise idle in this kernel; measured, the VALU count per tile falls from ~1000 to ~420 and
-// the kernel goes from issue-bound to DMA-bound.  This is not a GEMM reshaping of the problem:
-// the data stay in their row layout and every byte is still read from HBM exactly once.
+// otherwise idle in this kernel.  This is not a GEMM reshaping of the problem: the data stay in
+// their row layout and every byte is still read from HBM exactly once.
+//
+// NBUF = LDS buffers per wave for the quality tile: 2 = the DMA of tile t+1 overlaps the scan of
+// tile t inside the wave (8 waves per CU); 1 = a tile is loaded, scanned, then replaced, and the
+// overlap comes from having 16 waves per CU out of phase.  With -n (HAS_SEQ) the two buffers
+// hold the quality and the sequence tile of the same reads and each is refilled as soon as its
+// scan is over.
 //
 // ABLATE (diagnostic launches of tools/ablate.py only; the product always runs 0):
 //   1 = DMA + cut store only (no scan), 2 = scan only (tile loaded once, then reused)
-// __launch_bounds__(.., 2): at >= 2 waves per SIMD the register budget is <= 256, which makes hipcc
-// keep the MFMA accumulators in VGPRs (with AGPR accumulators every sign-bit collect would first
-// need a v_accvgpr_read, and the -T seed a v_accvgpr_write: +48 VALU per 32 windows).
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int ABLATE = 0>
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0>
 __global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                     unsigned long long *errword, sk_scan_args a)
 {
     static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
+    constexpr int LDS_BUFS = HAS_SEQ ? 2 : NBUF;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: tells the compiler this is one value per wave, so that the tile index and
+    // everything derived from it (addresses, piece counts, loop and switch conditions) live in
+    // SGPRs and branch on the scalar unit instead of being carried through the vector ALU
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int waves_per_block = blockDim.x >> 6;
     const uint32_t stride = a.stride;
     const uint32_t buf_bytes = 64u * stride + SK_TILE_SLACK;
-    uint8_t *buf0 = lds + (size_t)wave * 2u * buf_bytes;
-    uint8_t *buf1 = buf0 + buf_bytes;
+    uint8_t *buf0 = lds + (size_t)wave * LDS_BUFS * buf_bytes;
+    uint8_t *buf1 = LDS_BUFS > 1 ? buf0 + buf_bytes : buf0;
 
     const uint64_t n_tiles = (a.n_reads + 63) >> 6;
     const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
@@ -202,13 +222,16 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const uint32_t cthr4 = splat((uint32_t)a.cthr);
     const int range = a.qmax - a.qmin;
 
-    // ---- constants of the matrix path (uniform L => uniform w)
+    // uniform-length batches: one length, one window width, one window count for every lane
+    const int Lu = (int)a.read_len;
+    const bool scan_u = Lu > 0 && Lu >= a.lthr; // reference trim.cpp:21
+    const int wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
+
+    // ---- constants of the matrix path
     sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0};
     sk_v16i negT;
     const int half = lane >> 5;
     if (MFMA) {
-        const int Lu = (int)a.read_len;
-        const int wu = Lu / 10 ? Lu / 10 : Lu;
         // this lane supplies row m' = lane&31 of A; the hardware puts row m' into accumulator
         // reg r of lane half hh with m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be
         // window 16*hh + r
@@ -245,7 +268,7 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         const uint64_t r = (t << 6) + lane;
         len_next = r < a.n_reads ? (int)min(lengths[r], stride) : 0;
     }
-    int parity = 0; // !HAS_SEQ: which buffer holds Q(t)
+    int parity = 0; // NBUF == 2: which buffer holds Q(t)
 
     for (; t < n_tiles; t += wave_count) {
         const uint64_t r0 = t << 6;
@@ -257,47 +280,51 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         const uint8_t *tile;
 
         const bool active = r < a.n_reads;
-        int L = 0;
-        if (active) L = UNIFORM ? (int)a.read_len : len_next;
-        if (!UNIFORM && more) { // next tile's lengths: an ordinary load, issued ahead of the DMA
-            const uint64_t rn = (tn << 6) + lane;
-            len_next = rn < a.n_reads ? (int)min(lengths[rn], stride) : 0;
+        int Lv = 0; // mixed lengths: this lane's length
+        if (!UNIFORM) {
+            if (active) Lv = len_next;
+            if (more) { // next tile's lengths: an ordinary load, issued ahead of the DMA
+                const uint64_t rn = (tn << 6) + lane;
+                len_next = rn < a.n_reads ? (int)min(lengths[rn], stride) : 0;
+            }
         }
 
         if (HAS_SEQ) {
             tile = buf0;
             // outstanding, oldest first: Q(t), S(t) [, store(t-1) before them]
             wait_vmcnt(tile_pieces(cur_bytes));
+        } else if (NBUF == 1 || ABLATE == 2) {
+            tile = buf0;
+            wait_vmcnt(0);
         } else {
             tile = parity ? buf1 : buf0;
             uint8_t *other = parity ? buf0 : buf1;
-            if (ABLATE == 2) {
-                tile = buf0;
-                wait_vmcnt(0);
-            } else {
-                if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
-                wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
-                parity ^= 1;
-            }
+            if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
+            wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
+            parity ^= 1;
         }
         const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
         if (ABLATE == 1) {
-            if (active) out[r] = sk_cut_dev{(int)row[0], (int)row[1]};
+            const sk_cut_dev dummy{(int)row[0], (int)row[1]};
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (NBUF == 1 && more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+            if (active) out[r] = dummy;
             cur_bytes = next_bytes;
             continue;
         }
 
-        // reference trim.cpp:21 -- shorter than -l: discarded before any quality is read
-        const bool scanned = active && L > 0 && L >= a.lthr;
-        if (!scanned) L = 0;
+        // Lanes past the end of the batch scan whatever sits in their LDS row (every read below
+        // is bounded) and are dropped at the store; in uniform batches that keeps L, w and the
+        // window count in scalar registers.
+        const bool scanned = UNIFORM ? (active && scan_u) : (active && Lv > 0 && Lv >= a.lthr);
+        const int L = UNIFORM ? (scan_u ? Lu : 0) : (scanned ? Lv : 0);
         int w = L / 10; // trim.cpp:8 (int)(0.1*L) == L/10
         if (w == 0) w = L; // trim.cpp:30
-        const int nwin = scanned ? L - w + 1 : 0;
+        const int nwin = (UNIFORM ? scan_u : scanned) ? L - w + 1 : 0;
         const int m = w >> 2, sh = w & 3;
-        const int Lmax = UNIFORM ? (int)a.read_len : wave_max(L);
-        const int wmax = UNIFORM ? (Lmax / 10 ? Lmax / 10 : Lmax) : wave_max(w);
-        const int nwinmax = UNIFORM ? Lmax - wmax + 1 : wave_max(nwin);
+        const int Lmax = UNIFORM ? L : wave_max(L);
+        const int wmax = UNIFORM ? w : wave_max(w);
+        const int nwinmax = UNIFORM ? nwin : wave_max(nwin);
 
         // ---- range check of the whole read in 2 ops per dword: for a char c in [min,max],
         // |c-min| + |c-max| == max-min, and it is larger for every other byte value, so the
@@ -307,13 +334,29 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         {
             int k = 0;
             if (UNIFORM) {
-                for (; 4 * (k + 1) <= Lmax; ++k) {
-                    const uint32_t x = row[k];
-                    sad = __builtin_amdgcn_sad_u8(x, min4, sad);
-                    sad = __builtin_amdgcn_sad_u8(x, max4, sad);
+                const int full = Lmax >> 2; // whole dwords; rows are 8-byte aligned
+                const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
+                for (; k + 8 <= full; k += 8) { // 4 x ds_read_b64 in flight, then 16 SADs
+                    uint64_t x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = row64[(k >> 1) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        sad = __builtin_amdgcn_sad_u8((uint32_t)x[u], min4, sad);
+                        sad = __builtin_amdgcn_sad_u8((uint32_t)x[u], max4, sad);
+                        sad = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), min4, sad);
+                        sad = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), max4, sad);
+                    }
+                }
+                for (; k + 2 <= full; k += 2) {
+                    const uint64_t x = row64[k >> 1];
+                    sad = __builtin_amdgcn_sad_u8((uint32_t)x, min4, sad);
+                    sad = __builtin_amdgcn_sad_u8((uint32_t)x, max4, sad);
+                    sad = __builtin_amdgcn_sad_u8((uint32_t)(x >> 32), min4, sad);
+                    sad = __builtin_amdgcn_sad_u8((uint32_t)(x >> 32), max4, sad);
                 }
             }
-            for (; 4 * k < Lmax; ++k) { // per-lane masking: the last dword (UNIFORM) / mixed lengths
+            for (; 4 * k < Lmax; ++k) { // per-lane masking: the last dword(s) (UNIFORM) / mixed lengths
                 const uint32_t x = first_bytes(row[k], L - 4 * k, min4);
                 sad = __builtin_amdgcn_sad_u8(x, min4, sad);
                 sad = __builtin_amdgcn_sad_u8(x, max4, sad);
@@ -323,30 +366,26 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         }
         const bool bad = scanned && sad != 0;
 
-        // ---- all windows, 32 per trip: trim.cpp:34-81 without the breaks
-        bool found5 = a.no5 != 0; // with -x the 3' search starts at window 0 (trim.cpp:62)
-        bool done = false;
+        // ---- all windows, 32 per trip: trim.cpp:34-81 without the breaks.  Branch-free state
+        // step, so that the compiler can overlap it with the next trip's loads and MFMAs.
+        uint32_t found5 = a.no5 ? 1u : 0u; // with -x the 3' search starts at window 0 (trim.cpp:62)
+        uint32_t done = 0;
         int i0 = 0, i1 = 0;
-        // 32-window state step; bit (31 - s) of M: window base+s is below the threshold
+        // bit (31 - s) of M: window base+s is below the threshold
         auto step32 = [&](uint32_t M, int base) {
             const int nv = nwin - base;
             const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
-            uint32_t lt = M & vmask;
+            const uint32_t lt = M & vmask;
             const uint32_t ge = ~M & vmask;
-            if (!found5) {
-                if (ge) { // trim.cpp:42
-                    const int p = __builtin_clz(ge);
-                    i0 = base + p;
-                    found5 = true;
-                    lt &= (p == 31) ? 0u : (~0u >> (p + 1));
-                } else {
-                    lt = 0;
-                }
-            }
-            if (found5 && !done && lt) { // trim.cpp:61
-                i1 = base + __builtin_clz(lt);
-                done = true;
-            }
+            const uint32_t p = (uint32_t)__builtin_clz(ge | 1u); // first window at/above the threshold
+            const bool take5 = !found5 && ge != 0;               // trim.cpp:42
+            i0 = take5 ? base + (int)p : i0;
+            const uint32_t after = lt & (0x7fffffffu >> p);      // strictly after that window
+            const uint32_t cand = found5 ? lt : (take5 ? after : 0u);
+            found5 |= take5 ? 1u : 0u;
+            const bool take3 = !done && cand != 0; // trim.cpp:61 (cand != 0 implies found5)
+            i1 = take3 ? base + __builtin_clz(cand | 1u) : i1;
+            done |= take3 ? 1u : 0u;
         };
 
         if (MFMA) {
@@ -415,21 +454,25 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         }
         const bool have5 = found5 && !a.no5;
 
-        // ---- the in-window searches: trim.cpp:46-51 and :65-70
+        // ---- the in-window searches: trim.cpp:46-51 and :65-70.
+        // 5': first char >= threshold at or after i0; 3': first char < threshold at or after i1.
+        // Both exist inside their window (its average is on that side of the threshold), i.e. in
+        // the dwords k..k+trips-1.  Addresses do not depend on the data, so the reads pipeline.
         int five = 0, three = L;
         {
-            // 5': first char >= threshold at or after i0; 3': first char < threshold at or after i1.
-            // Both exist inside their window (its average is on that side of the threshold).
-            int k5 = i0 >> 2, k3 = i1 >> 2;
-            uint32_t g5 = have5 ? ge_flags(row[k5], cthr4) & (~0u << (8 * (i0 & 3))) : H4;
-            uint32_t g3 = done ? (ge_flags(row[k3], cthr4) ^ H4) & (~0u << (8 * (i1 & 3))) : H4;
+            const int k5 = i0 >> 2, k3 = i1 >> 2;
             const int trips = (wmax + 3) / 4 + 1;
+            int hit5 = -1, hit3 = -1;
+            uint32_t keep5 = ~0u << (8 * (i0 & 3)), keep3 = ~0u << (8 * (i1 & 3));
             for (int it = 0; it < trips; ++it) {
-                if (g5 == 0) { ++k5; g5 = ge_flags(row[k5], cthr4); }
-                if (g3 == 0) { ++k3; g3 = ge_flags(row[k3], cthr4) ^ H4; }
+                const uint32_t g5 = ge_flags(row[k5 + it], cthr4) & keep5;
+                const uint32_t g3 = (ge_flags(row[k3 + it], cthr4) ^ H4) & keep3;
+                keep5 = keep3 = ~0u;
+                if (hit5 < 0 && g5) hit5 = 4 * (k5 + it) + (__builtin_ctz(g5) >> 3);
+                if (hit3 < 0 && g3) hit3 = 4 * (k3 + it) + (__builtin_ctz(g3) >> 3);
             }
-            if (have5) five = 4 * k5 + ((__builtin_ctz(g5 | 0x80000000u)) >> 3);
-            if (done) three = 4 * k3 + ((__builtin_ctz(g3 | 0x80000000u)) >> 3);
+            if (have5 && hit5 >= 0) five = hit5;
+            if (done && hit3 >= 0) three = hit3;
         }
 
         // ---- range error: only if the first bad char is one the reference would have read
@@ -464,6 +507,11 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             else if (Ni != INF) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane); // S(t+1)
+        } else if (NBUF == 1 && ABLATE != 2) {
+            // single buffer: every LDS read of this tile is done, refill it now -- the cut store
+            // below and the other waves of the CU cover the DMA latency
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
         }
 
         // ---- trim.cpp:103-108
@@ -589,71 +637,90 @@ sk_scan_wave_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 // ------------------------------------------------------------------------------------------
 // launchers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------
+namespace {
+
+int tile_nbuf_default()
+{
+    // diagnostic override (tools/ablate.py, A/B runs): SK_TILE_NBUF=1|2
+    static const int v = [] {
+        const char *e = getenv("SK_TILE_NBUF");
+        return (e && (*e == '1' || *e == '2')) ? *e - '0' : SK_TILE_NBUF_DEFAULT;
+    }();
+    return v;
+}
+
+template <typename K>
+hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
+                              sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a, int cu_count,
+                              int per_cu_cap, hipStream_t stream)
+{
+    // single-wave workgroups (waves never synchronise with each other); as many per CU as the
+    // 160 KiB of LDS and the 32-wave limit allow
+    const uint32_t lds_bytes = (uint32_t)bufs * (64u * a->stride + SK_TILE_SLACK);
+    if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
+    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid == 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, lengths, out, errword, *a);
+    return hipGetLastError();
+}
+
+} // namespace
+
 extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream)
 {
-    // Two LDS buffers per wave.  Waves never synchronise with each other, so one wave per
-    // workgroup: up to 8 single-wave workgroups per CU, as the 160 KiB allow (measured 10 %
-    // faster than 2 workgroups of 4 waves at the same LDS footprint).
-    const uint32_t wave_lds = 2u * (64u * a->stride + SK_TILE_SLACK);
-    if (wave_lds > SK_LDS_PER_CU) return hipErrorInvalidValue;
-    const int waves = 1;
-    const uint32_t lds_bytes = (uint32_t)waves * wave_lds;
-    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    if (per_cu > 8) per_cu = 8;
-    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
-    const uint64_t blocks_needed = (n_tiles + waves - 1) / waves;
-    uint64_t grid = (uint64_t)cu_count * per_cu;
-    if (grid > blocks_needed) grid = blocks_needed;
-    if (grid == 0) return hipSuccess;
     const bool uniform = lengths == nullptr;
     const bool has_seq = a->truncn != 0;
     // the matrix path: one window width for the whole batch, band within two 32-position blocks
     const uint32_t wu = a->read_len / 10 ? a->read_len / 10 : a->read_len;
     const bool mfma = uniform && wu <= 33 && a->read_len > 0;
-    auto launch = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64u * waves), lds_bytes, stream, qual, seq, lengths, out,
-                           errword, *a);
-        return hipGetLastError();
-    };
-    if (mfma) return has_seq ? launch(sk_scan_tile_kernel<true, true, true>) : launch(sk_scan_tile_kernel<true, false, true>);
-    if (uniform) return has_seq ? launch(sk_scan_tile_kernel<true, true>) : launch(sk_scan_tile_kernel<true, false>);
-    return has_seq ? launch(sk_scan_tile_kernel<false, true>) : launch(sk_scan_tile_kernel<false, false>);
+    const int nbuf = tile_nbuf_default();
+#define SK_GO(KERN, BUFS) launch_tile_kernel(KERN, BUFS, qual, seq, lengths, out, errword, a, cu_count, 0, stream)
+    if (has_seq) {
+        if (mfma) return SK_GO((sk_scan_tile_kernel<true, true, true, 2>), 2);
+        if (uniform) return SK_GO((sk_scan_tile_kernel<true, true, false, 2>), 2);
+        return SK_GO((sk_scan_tile_kernel<false, true, false, 2>), 2);
+    }
+    if (nbuf == 1) {
+        if (mfma) return SK_GO((sk_scan_tile_kernel<true, false, true, 1>), 1);
+        if (uniform) return SK_GO((sk_scan_tile_kernel<true, false, false, 1>), 1);
+        return SK_GO((sk_scan_tile_kernel<false, false, false, 1>), 1);
+    }
+    if (mfma) return SK_GO((sk_scan_tile_kernel<true, false, true, 2>), 2);
+    if (uniform) return SK_GO((sk_scan_tile_kernel<true, false, false, 2>), 2);
+    return SK_GO((sk_scan_tile_kernel<false, false, false, 2>), 2);
+#undef SK_GO
 }
 
-// diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py)
+// diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py).
+// mode = ablate + 10*(vector-ALU path instead of matrix path) + 100*(single buffer)
 extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cut_dev *out, unsigned long long *errword,
                                             const sk_scan_args *a, int cu_count, int waves, int per_cu, hipStream_t stream)
 {
-    const uint32_t wave_lds = 2u * (64u * a->stride + SK_TILE_SLACK);
-    if (waves < 1) waves = SK_TILE_WAVES;
-    const uint32_t lds_bytes = (uint32_t)waves * wave_lds;
-    if (per_cu < 1) per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
-    uint64_t grid = (uint64_t)cu_count * per_cu;
-    const uint64_t blocks_needed = (n_tiles + waves - 1) / waves;
-    if (grid > blocks_needed) grid = blocks_needed;
-    auto launch = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64u * waves), lds_bytes, stream, qual,
-                           (const uint8_t *)nullptr, (const uint32_t *)nullptr, out, errword, *a);
-        return hipGetLastError();
-    };
-    // modes 0..2: matrix path (whole / DMA only / scan only); 10..12: the same on the vector-ALU path
+    (void)waves;
+#define SK_GO(KERN, BUFS) launch_tile_kernel(KERN, BUFS, qual, nullptr, nullptr, out, errword, a, cu_count, per_cu, stream)
     switch (mode) {
-    case 0: return launch(sk_scan_tile_kernel<true, false, true, 0>);
-    case 1: return launch(sk_scan_tile_kernel<true, false, true, 1>);
-    case 2: return launch(sk_scan_tile_kernel<true, false, true, 2>);
-    case 10: return launch(sk_scan_tile_kernel<true, false, false, 0>);
-    case 12: return launch(sk_scan_tile_kernel<true, false, false, 2>);
+    case 0: return SK_GO((sk_scan_tile_kernel<true, false, true, 2, 0>), 2);
+    case 1: return SK_GO((sk_scan_tile_kernel<true, false, true, 2, 1>), 2);
+    case 2: return SK_GO((sk_scan_tile_kernel<true, false, true, 2, 2>), 2);
+    case 10: return SK_GO((sk_scan_tile_kernel<true, false, false, 2, 0>), 2);
+    case 12: return SK_GO((sk_scan_tile_kernel<true, false, false, 2, 2>), 2);
+    case 100: return SK_GO((sk_scan_tile_kernel<true, false, true, 1, 0>), 1);
+    case 101: return SK_GO((sk_scan_tile_kernel<true, false, true, 1, 1>), 1);
+    case 102: return SK_GO((sk_scan_tile_kernel<true, false, true, 1, 2>), 1);
+    case 110: return SK_GO((sk_scan_tile_kernel<true, false, false, 1, 0>), 1);
     default: return hipErrorInvalidValue;
     }
+#undef SK_GO
 }
 
 extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,

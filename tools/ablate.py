@@ -22,19 +22,21 @@ err = torch.full((1,), -1, dtype=torch.int64, device=dev)
 a = Args(n, 152, 150, 33, 126, 53, 53, 53, 20, 0, 0)
 s = torch.cuda.Stream(dev)
 torch.cuda.synchronize()
-NAMES = {0: "mfma full", 1: "dma-only", 2: "mfma scan-only", 10: "valu full", 12: "valu scan-only"}
-for waves, per_cu in ((1, 8), (1, 6), (1, 4), (2, 4)):
-    for mode in (0, 1, 2, 10, 12):
+NAMES = {0: "2buf mfma full", 1: "2buf dma-only", 2: "2buf mfma scan-only", 10: "2buf valu full", 12: "2buf valu scan-only",
+         100: "1buf mfma full", 101: "1buf dma-only", 102: "1buf mfma scan-only", 110: "1buf valu full"}
+CONFIGS = [(8, (0, 1, 2, 10, 12)), (16, (100, 101, 102, 110)), (12, (100,)), (8, (100,)), (6, (0,))]
+for per_cu, modes in CONFIGS:
+    for mode in modes:
         ts = []
-        for it in range(8):
+        for it in range(10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-            rc = lib.sk_launch_tile_ablate(mode, q.data_ptr(), out.data_ptr(), err.data_ptr(), C.byref(a), 256, waves, per_cu, s.cuda_stream)
+            rc = lib.sk_launch_tile_ablate(mode, q.data_ptr(), out.data_ptr(), err.data_ptr(), C.byref(a), 256, 1, per_cu, s.cuda_stream)
             e1.record(s)
             s.synchronize()
             assert rc == 0, rc
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         ms = ts[len(ts) // 2]
-        print("waves/block %d blocks/CU %d mode %d (%s): %.3f ms  %.0f GB/s algorithmic" %
-              (waves, per_cu, mode, NAMES[mode], ms, 158 * n / ms / 1e6), flush=True)
+        print("workgroups/CU %2d mode %3d (%-20s): %.3f ms  %.0f GB/s algorithmic" %
+              (per_cu, mode, NAMES[mode], ms, 158 * n / ms / 1e6), flush=True)
