@@ -72,6 +72,23 @@ __device__ __forceinline__ uint32_t keep_first(uint32_t flags, int n)
     return n >= 4 ? flags : (n <= 0 ? 0u : flags & ((1u << (8 * n)) - 1u));
 }
 
+// v_ffbh_u32 / v_ffbl_b32: index of the first set bit from the top / from the bottom, and
+// 0xFFFFFFFF for an empty mask (what __builtin_clz/ctz leave undefined and would guard with an
+// extra instruction).  Combined with saturating adds, "no hit" stays 0xFFFFFFFF through a min().
+__device__ __forceinline__ uint32_t ffbh_or_none(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t ffbl_or_none(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+constexpr uint32_t NONE = 0xffffffffu;
+
 __device__ __forceinline__ int wave_min(int v)
 {
 #pragma unroll
@@ -93,6 +110,12 @@ __device__ __forceinline__ void report_error(unsigned long long *errword, uint64
     atomicMin(errword, key);
 }
 
+// cache policy of the tile DMA (the aux operand of global_load_lds): 0 = default, 2 = nt.
+// Every tile byte is read exactly once, so nt: measured -9 % on the DMA-only floor and -8 % on the
+// whole kernel against the default policy (interleaved A/B on one device, tools/ablate.py).
+#ifndef SK_DMA_AUX
+#define SK_DMA_AUX 2
+#endif
 using gptr_t = const __attribute__((address_space(1))) void *;
 using lptr_t = __attribute__((address_space(3))) void *;
 
@@ -110,15 +133,15 @@ __device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, ui
     for (; p + 4 <= pieces; p += 4) {
         gptr_t g = (gptr_t)(sp + (size_t)p * 1024);
         lptr_t l = (lptr_t)(dst + p * 1024);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, SK_DMA_AUX);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, SK_DMA_AUX);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, SK_DMA_AUX);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, SK_DMA_AUX);
     }
     for (; p < pieces; ++p)
-        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, SK_DMA_AUX);
     if ((uint32_t)lane < (nfull & 63u))
-        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, SK_DMA_AUX);
     const uint32_t tail = (bytes & 15u) >> 2; // 0..3 dwords after the last full 16-byte chunk
     if ((uint32_t)lane < tail)
         __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)nfull * 16 + lane * 4), (lptr_t)(dst + nfull * 16),
@@ -249,7 +272,13 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         bandA1 = f1.v;
         const int T = a.craw * wu;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) negT[i] = -T;
+        for (int i = 0; i < 16; ++i) {
+            int seed = -T;
+            // opaque to the compiler: otherwise it keeps this uniform value in SGPRs and copies it
+            // into 16 VGPRs again before every MFMA pair (8 v_mov_b64 per 32 windows)
+            asm volatile("" : "+v"(seed));
+            negT[i] = seed;
+        }
     }
 
     auto tile_bytes_of = [&](uint64_t t) -> uint32_t {
@@ -368,24 +397,25 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 
         // ---- all windows, 32 per trip: trim.cpp:34-81 without the breaks.  Branch-free state
         // step, so that the compiler can overlap it with the next trip's loads and MFMAs.
-        uint32_t found5 = a.no5 ? 1u : 0u; // with -x the 3' search starts at window 0 (trim.cpp:62)
-        uint32_t done = 0;
-        int i0 = 0, i1 = 0;
+        // i0u / i1u: the 5' and the 3' window, NONE until found (a min() over the trips keeps
+        // the first one, because later trips can only offer larger indices)
+        uint32_t i0u = NONE, i1u = NONE;
         // bit (31 - s) of M: window base+s is below the threshold
         auto step32 = [&](uint32_t M, int base) {
             const int nv = nwin - base;
             const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
             const uint32_t lt = M & vmask;
-            const uint32_t ge = ~M & vmask;
-            const uint32_t p = (uint32_t)__builtin_clz(ge | 1u); // first window at/above the threshold
-            const bool take5 = !found5 && ge != 0;               // trim.cpp:42
-            i0 = take5 ? base + (int)p : i0;
-            const uint32_t after = lt & (0x7fffffffu >> p);      // strictly after that window
-            const uint32_t cand = found5 ? lt : (take5 ? after : 0u);
-            found5 |= take5 ? 1u : 0u;
-            const bool take3 = !done && cand != 0; // trim.cpp:61 (cand != 0 implies found5)
-            i1 = take3 ? base + __builtin_clz(cand | 1u) : i1;
-            done |= take3 ? 1u : 0u;
+            uint32_t cand = lt; // with -x the 3' search starts at window 0 (trim.cpp:62)
+            if (!a.no5) {
+                const uint32_t ge = ~M & vmask;
+                i0u = min(i0u, __builtin_elementwise_add_sat(ffbh_or_none(ge), (uint32_t)base)); // trim.cpp:42
+                // windows of this trip strictly after i0: the low (base+31 - i0) bits, all 32 if
+                // i0 lies in an earlier trip, none while it is not found
+                const uint32_t width = __builtin_elementwise_sub_sat((uint32_t)(base + 31), i0u);
+                const uint32_t low = (1u << (width & 31u)) - 1u;
+                cand = lt & (width >= 32u ? ~0u : low);
+            }
+            i1u = min(i1u, __builtin_elementwise_add_sat(ffbh_or_none(cand), (uint32_t)base)); // trim.cpp:61
         };
 
         if (MFMA) {
@@ -452,27 +482,34 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 step32(M, base);
             }
         }
-        const bool have5 = found5 && !a.no5;
+        const bool found5 = a.no5 || i0u != NONE;
+        const bool have5 = !a.no5 && i0u != NONE;
+        const bool done = i1u != NONE;
+        const int i0 = have5 ? (int)i0u : 0, i1 = done ? (int)i1u : 0;
 
         // ---- the in-window searches: trim.cpp:46-51 and :65-70.
         // 5': first char >= threshold at or after i0; 3': first char < threshold at or after i1.
         // Both exist inside their window (its average is on that side of the threshold), i.e. in
-        // the dwords k..k+trips-1.  Addresses do not depend on the data, so the reads pipeline.
+        // the dwords k..k+trips-1.  Addresses do not depend on the data, so the reads pipeline;
+        // a hit is tracked as the bit index of its flag (8*pos + 7), NONE until found.
         int five = 0, three = L;
         {
             const int k5 = i0 >> 2, k3 = i1 >> 2;
             const int trips = (wmax + 3) / 4 + 1;
-            int hit5 = -1, hit3 = -1;
+            uint32_t h5 = NONE, h3 = NONE;
+            uint32_t b5 = 32u * (uint32_t)k5, b3 = 32u * (uint32_t)k3;
             uint32_t keep5 = ~0u << (8 * (i0 & 3)), keep3 = ~0u << (8 * (i1 & 3));
             for (int it = 0; it < trips; ++it) {
                 const uint32_t g5 = ge_flags(row[k5 + it], cthr4) & keep5;
                 const uint32_t g3 = (ge_flags(row[k3 + it], cthr4) ^ H4) & keep3;
                 keep5 = keep3 = ~0u;
-                if (hit5 < 0 && g5) hit5 = 4 * (k5 + it) + (__builtin_ctz(g5) >> 3);
-                if (hit3 < 0 && g3) hit3 = 4 * (k3 + it) + (__builtin_ctz(g3) >> 3);
+                h5 = min(h5, __builtin_elementwise_add_sat(ffbl_or_none(g5), b5));
+                h3 = min(h3, __builtin_elementwise_add_sat(ffbl_or_none(g3), b3));
+                b5 += 32u;
+                b3 += 32u;
             }
-            if (have5 && hit5 >= 0) five = hit5;
-            if (done && hit3 >= 0) three = hit3;
+            if (have5 && h5 != NONE) five = (int)(h5 >> 3);
+            if (done && h3 != NONE) three = (int)(h3 >> 3);
         }
 
         // ---- range error: only if the first bad char is one the reference would have read
@@ -515,7 +552,7 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         }
 
         // ---- trim.cpp:103-108
-        if (!scanned || (!found5 && !a.no5) || (three - five < a.lthr)) {
+        if (!scanned || !found5 || (three - five < a.lthr)) {
             five = -1;
             three = -1;
         }

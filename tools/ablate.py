@@ -12,7 +12,7 @@ class Args(C.Structure):
                 ("qmax", C.c_int32), ("craw", C.c_int32), ("cthr", C.c_int32), ("cthr_raw", C.c_int32),
                 ("lthr", C.c_int32), ("no5", C.c_int32), ("truncn", C.c_int32)]
 
-lib = C.CDLL(os.path.join(ROOT, "sickle_amd", "libsickle_amd.so"))
+lib = C.CDLL(os.environ.get("SK_LIB", os.path.join(ROOT, "sickle_amd", "libsickle_amd.so")))
 lib.sk_launch_tile_ablate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.c_void_p]
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
@@ -25,6 +25,8 @@ torch.cuda.synchronize()
 NAMES = {0: "2buf mfma full", 1: "2buf dma-only", 2: "2buf mfma scan-only", 10: "2buf valu full", 12: "2buf valu scan-only",
          100: "1buf mfma full", 101: "1buf dma-only", 102: "1buf mfma scan-only", 110: "1buf valu full"}
 CONFIGS = [(8, (0, 1, 2, 10, 12)), (16, (100, 101, 102, 110)), (12, (100,)), (8, (100,)), (6, (0,))]
+if os.environ.get("SK_ABLATE_SHORT"):
+    CONFIGS = [(16, (100, 101, 102)), (8, (0, 1))]
 for per_cu, modes in CONFIGS:
     for mode in modes:
         ts = []
