@@ -63,6 +63,22 @@ def host_cores():
     return max(1, n)
 
 
+def pmc_traffic(n, length, kern_ms):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (tools/profile.sh ->
+    profiles/r01/pmc_latest.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes),
+    scaled to this run's read count; as GB/s over this run's kernel time.  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+        per_read = d["hbm_bytes_per_launch"]["total"] / 10_000_000.0
+        if length != 150:
+            return None, None
+        total = per_read * n
+        return total / (kern_ms * 1e-3) / 1e9, total
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(qual_host, n, stride, length, threads):
     """The CPU path timed beside the GPU: the reference's own sliding_window (oracle/_ref, kind
     "reference") when that prebuilt library travelled with the repo, else the oracle port."""
@@ -167,6 +183,7 @@ def main():
         total_reads = world * n * args.steps
         algo_bytes = (length + 8) * n  # L quality bytes read + one 8-byte cut pair written, per read
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+        traffic, traffic_bytes = pmc_traffic(n, length, kern_avg_ms)
         res = {
             "metric": "reads/sec trimmed (+ Gbases/sec), 150 bp SE Sanger q20 l20, inputs resident in HBM",
             "value": total_reads / elapsed, "unit": "reads/s",
@@ -180,7 +197,9 @@ def main():
             "kept": counts[0], "discarded": counts[1],
             "mean_bases_kept": counts[2] / max(1, counts[0]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_bytes_per_launch": traffic_bytes,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/pmc_latest.json",
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1],
                          "algorithmic_bytes_per_launch": algo_bytes},
         }

@@ -114,13 +114,14 @@ void sk_host_free(sk_ctx *ctx, void *p);
 /*
  * Device-resident batch: every pointer in *batch and `out` is a DEVICE pointer.  Enqueues
  * the scan on `hip_stream` (a hipStream_t; NULL = the context's compute stream) and
- * returns without waiting.  out[r] is written for every read; the error word is reset by
- * a memset node ahead of the kernel.
+ * returns without waiting.  out[r] is written for every read.  Range errors of all scans
+ * enqueued since the last sk_scan_device_finish accumulate in one device word (lowest read
+ * index wins); nothing but the kernel is enqueued here.
  */
 int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *batch,
                          sk_cut *out, void *hip_stream);
-/* Waits for the stream and reports the range error of the most recent sk_scan_device_async
- * on it: SK_OK, or SK_ERANGE with *err filled. */
+/* Waits for the stream and reports (and clears) the range error of the scans enqueued on it
+ * since the previous finish: SK_OK, or SK_ERANGE with *err filled. */
 int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err);
 
 /*

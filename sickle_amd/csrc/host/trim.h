@@ -10,7 +10,11 @@
 
 #include <zlib.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
+#include <initializer_list>
+#include <utility>
 #include <cstdio>
 #include <deque>
 #include <mutex>
@@ -33,6 +37,33 @@ public:
 private:
     FILE *fp = nullptr;
     gzFile gz = nullptr;
+};
+
+// Wall-clock accumulators per pipeline stage, printed to stderr when SICKLE_STAGE_TIMES=1.
+class StageClock {
+public:
+    class Scope {
+    public:
+        explicit Scope(StageClock &c) : clk(&c), t0(std::chrono::steady_clock::now()) {}
+        void stop()
+        {
+            if (!clk) return;
+            clk->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            clk = nullptr;
+        }
+        ~Scope() { stop(); }
+
+    private:
+        StageClock *clk;
+        std::chrono::steady_clock::time_point t0;
+    };
+    static void report(std::initializer_list<std::pair<const char *, StageClock *>> stages)
+    {
+        const char *e = getenv("SICKLE_STAGE_TIMES");
+        if (!e || !*e || *e == '0') return;
+        for (const auto &s : stages) fprintf(stderr, "[stage] %-16s %8.3f s\n", s.first, s.second->seconds);
+    }
+    double seconds = 0;
 };
 
 // bounded hand-off between pipeline stages

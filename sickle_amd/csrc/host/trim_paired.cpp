@@ -5,6 +5,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 
 // reference src/trim_paired.cpp:16-36
@@ -304,9 +305,11 @@ int Trim_Paired::trim_main()
     if (res != 0) return res;
 
     Channel<Work *> parsed(2), scanned(2);
+    StageClock clk_read, clk_frame, clk_pack, clk_wait, clk_out;
     std::thread reader([&] {
         // the batch loop of reference src/trim_paired.cpp:280-453, minus the worker threads
         while (true) {
+            StageClock::Scope rd(clk_read);
             Batch *batch = input->get_batch_buffering_lines();
             if (batch == NULL) break;
             Batch *batch2 = NULL;
@@ -323,6 +326,8 @@ int Trim_Paired::trim_main()
                     break;
                 }
             }
+            rd.stop();
+            StageClock::Scope fr(clk_frame);
             Work *w = new Work();
             w->batch = batch;
             w->batch2 = batch2;
@@ -353,6 +358,7 @@ int Trim_Paired::trim_main()
                 delete w;
                 break;
             }
+            fr.stop();
             parsed.push(w);
         }
         parsed.close();
@@ -360,6 +366,7 @@ int Trim_Paired::trim_main()
     std::thread writer([&] {
         Work *w;
         while (scanned.pop(w)) {
+            StageClock::Scope o(clk_out);
             output_paired(*w);
             delete w;
         }
@@ -369,7 +376,11 @@ int Trim_Paired::trim_main()
     auto finish = [&](int slot) {
         Work *w = inflight[slot];
         if (!w) return;
-        const cutsites *cs = wait_scan(slot, w->reads);
+        const cutsites *cs;
+        {
+            StageClock::Scope wt(clk_wait);
+            cs = wait_scan(slot, w->reads);
+        }
         w->cuts.assign(cs, cs + w->reads.size());
         inflight[slot] = nullptr;
         scanned.push(w);
@@ -379,7 +390,10 @@ int Trim_Paired::trim_main()
     while (parsed.pop(w)) {
         const int slot = i % kSlots;
         finish(slot);
-        submit_scan(slot, w->reads);
+        {
+            StageClock::Scope pk(clk_pack);
+            submit_scan(slot, w->reads);
+        }
         inflight[slot] = w;
         ++i;
     }
@@ -387,6 +401,8 @@ int Trim_Paired::trim_main()
     scanned.close();
     reader.join();
     writer.join();
+    StageClock::report({{"read+index", &clk_read}, {"frame", &clk_frame}, {"pack+submit", &clk_pack},
+                        {"device wait", &clk_wait}, {"classify+write", &clk_out}});
 
     if (!quiet) { // reference src/trim_paired.cpp:464-476
         if (infn && infn2) fprintf(stdout, "\nPE forward file: %s\nPE reverse file: %s\n", infn, infn2);

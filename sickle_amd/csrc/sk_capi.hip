@@ -127,17 +127,24 @@ bool tile_eligible(const sk_batch *b)
            (reinterpret_cast<uintptr_t>(b->qual) & 15) == 0 && (!b->seq || (reinterpret_cast<uintptr_t>(b->seq) & 15) == 0);
 }
 
-// enqueue: reset error word, kernel.  All pointers are device pointers.
+// enqueue the kernel.  All pointers are device pointers.  The error word is "no error" on
+// entry: it is reset when the context is created and again by whoever reads it
+// (reset_error_word), so nothing but the kernel sits on the launch path.
 int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_dev *out, unsigned long long *d_err,
                  hipStream_t stream)
 {
-    SK_HIP(ctx, hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), stream));
     if (a->n_reads == 0) return SK_OK;
     const uint8_t *seq = a->truncn ? b->seq : nullptr;
     if (tile_eligible(b))
         SK_HIP(ctx, sk_launch_tile(b->qual, seq, b->lengths, out, d_err, a, ctx->cu_count, stream));
     else
         SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, a, ctx->cu_count, stream));
+    return SK_OK;
+}
+
+int reset_error_word(sk_ctx *ctx, unsigned long long *d_err, hipStream_t stream)
+{
+    SK_HIP(ctx, hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), stream));
     return SK_OK;
 }
 
@@ -249,11 +256,13 @@ int sk_create(int device, int slots, sk_ctx **out)
     SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
     SK_TRY(hipMalloc(&ctx->d_err, sizeof(unsigned long long)));
+    SK_TRY(hipMemset(ctx->d_err, 0xff, sizeof(unsigned long long)));
     SK_TRY(hipHostMalloc(&ctx->h_err, sizeof(unsigned long long), hipHostMallocDefault));
     *ctx->h_err = kNoError;
     ctx->slots.resize((size_t)slots);
     for (Slot &s : ctx->slots) {
         SK_TRY(hipMalloc(&s.d_err, sizeof(unsigned long long)));
+        SK_TRY(hipMemset(s.d_err, 0xff, sizeof(unsigned long long)));
         SK_TRY(hipHostMalloc(&s.h_err, sizeof(unsigned long long), hipHostMallocDefault));
         SK_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         SK_TRY(hipEventCreateWithFlags(&s.finished, hipEventDisableTiming));
@@ -338,6 +347,8 @@ int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err)
     if (!ctx) return SK_EINVAL;
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->compute;
     SK_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    int rc = reset_error_word(ctx, ctx->d_err, stream);
+    if (rc != SK_OK) return rc;
     SK_HIP(ctx, hipStreamSynchronize(stream));
     return decode_error(*ctx->h_err, err);
 }
@@ -384,6 +395,8 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
     if (rc != SK_OK) return rc;
     if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));
     SK_HIP(ctx, hipMemcpyAsync(s.h_err, s.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->compute));
+    rc = reset_error_word(ctx, s.d_err, ctx->compute);
+    if (rc != SK_OK) return rc;
     SK_HIP(ctx, hipEventRecord(s.finished, ctx->compute));
     s.busy = true;
     return SK_OK;

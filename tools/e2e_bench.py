@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""End-to-end CLI timing on the GPU box: this repo's `sickle pe` (HIP) against the compiled
+reference CLI (oracle/_ref/sickle, when it travelled with the repo) on the same synthetic
+two-file paired input, outputs compared byte for byte.  Not part of bench.py's metric (that is
+the HBM-resident scan); this is the PCIe- and parse-inclusive number DESIGN.md quotes."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sickle_amd import synth  # noqa: E402
+
+NEW = os.path.join(ROOT, "sickle_amd", "sickle")
+REF = os.path.join(ROOT, "oracle", "_ref", "sickle")
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 22), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def write_pair(d, n, chunk=250_000):
+    p1, p2 = os.path.join(d, "R1.fastq"), os.path.join(d, "R2.fastq")
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for a in range(0, n, chunk):
+            m = min(chunk, n - a)
+            s1, q1 = synth.make_reads(1000 + a, m, 150, "sanger")
+            s2, q2 = synth.make_reads(5000 + a, m, 150, "sanger")
+            f1.write(synth.fastq_bytes(s1, q1, start=a, suffix="/1"))
+            f2.write(synth.fastq_bytes(s2, q2, start=a, suffix="/2"))
+    return p1, p2
+
+
+def run(binary, d, tag, p1, p2, threads):
+    outs = [os.path.join(d, "%s_%s.fastq" % (tag, k)) for k in ("o1", "o2", "os")]
+    t0 = time.perf_counter()
+    pr = subprocess.run([binary, "pe", "-f", p1, "-r", p2, "-t", "sanger", "-o", outs[0], "-p", outs[1], "-s", outs[2],
+                         "-a", str(threads)], capture_output=True)
+    dt = time.perf_counter() - t0
+    assert pr.returncode == 0, pr.stderr.decode()[-500:]
+    return dt, [md5(o) for o in outs]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    res = {"pairs": n, "reads": 2 * n}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        p1, p2 = write_pair(d, n)
+        res["input_bytes"] = os.path.getsize(p1) + os.path.getsize(p2)
+        run(NEW, d, "warm", p1, p2, 1)  # first touch of the GPU runtime and the page cache
+        t_new, m_new = run(NEW, d, "new", p1, p2, 1)
+        res["new_s"] = t_new
+        res["new_reads_per_s"] = 2 * n / t_new
+        if os.path.exists(REF):
+            t_ref1, m_ref1 = run(REF, d, "ref1", p1, p2, 1)
+            res["ref_a1_s"] = t_ref1
+            res["ref_a1_reads_per_s"] = 2 * n / t_ref1
+            res["identical_to_ref_a1"] = m_ref1 == m_new
+            cores = len(os.sched_getaffinity(0))
+            cores = min(cores, 16)
+            t_refn, _ = run(REF, d, "refn", p1, p2, cores)
+            res["ref_aN_s"] = t_refn
+            res["ref_aN_threads"] = cores
+            res["ref_aN_reads_per_s"] = 2 * n / t_refn
+            res["speedup_vs_ref_a1"] = t_ref1 / t_new
+            res["speedup_vs_ref_aN"] = t_refn / t_new
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
