@@ -400,13 +400,14 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         // i0u / i1u: the 5' and the 3' window, NONE until found (a min() over the trips keeps
         // the first one, because later trips can only offer larger indices)
         uint32_t i0u = NONE, i1u = NONE;
+        bool all_have5 = false; // wave-uniform
         // bit (31 - s) of M: window base+s is below the threshold
         auto step32 = [&](uint32_t M, int base) {
             const int nv = nwin - base;
             const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
             const uint32_t lt = M & vmask;
             uint32_t cand = lt; // with -x the 3' search starts at window 0 (trim.cpp:62)
-            if (!a.no5) {
+            if (!a.no5 && !all_have5) {
                 const uint32_t ge = ~M & vmask;
                 i0u = min(i0u, __builtin_elementwise_add_sat(ffbh_or_none(ge), (uint32_t)base)); // trim.cpp:42
                 // windows of this trip strictly after i0: the low (base+31 - i0) bits, all 32 if
@@ -414,6 +415,8 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 const uint32_t width = __builtin_elementwise_sub_sat((uint32_t)(base + 31), i0u);
                 const uint32_t low = (1u << (width & 31u)) - 1u;
                 cand = lt & (width >= 32u ? ~0u : low);
+                // once every lane has its 5' window, later trips need neither the search nor the mask
+                all_have5 = __builtin_amdgcn_ballot_w64(i0u == NONE) == 0;
             }
             i1u = min(i1u, __builtin_elementwise_add_sat(ffbh_or_none(cand), (uint32_t)base)); // trim.cpp:61
         };
@@ -496,20 +499,19 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         {
             const int k5 = i0 >> 2, k3 = i1 >> 2;
             const int trips = (wmax + 3) / 4 + 1;
-            uint32_t h5 = NONE, h3 = NONE;
-            uint32_t b5 = 32u * (uint32_t)k5, b3 = 32u * (uint32_t)k3;
-            uint32_t keep5 = ~0u << (8 * (i0 & 3)), keep3 = ~0u << (8 * (i1 & 3));
-            for (int it = 0; it < trips; ++it) {
-                const uint32_t g5 = ge_flags(row[k5 + it], cthr4) & keep5;
-                const uint32_t g3 = (ge_flags(row[k3 + it], cthr4) ^ H4) & keep3;
-                keep5 = keep3 = ~0u;
-                h5 = min(h5, __builtin_elementwise_add_sat(ffbl_or_none(g5), b5));
-                h3 = min(h3, __builtin_elementwise_add_sat(ffbl_or_none(g3), b3));
-                b5 += 32u;
-                b3 += 32u;
+            const uint32_t *r5 = row + k5, *r3 = row + k3;
+            // bit index of the first hit RELATIVE to dword k (8*byte + 7 + 32*trip), NONE until found
+            uint32_t h5 = ffbl_or_none(ge_flags(r5[0], cthr4) & (~0u << (8 * (i0 & 3))));
+            uint32_t h3 = ffbl_or_none((ge_flags(r3[0], cthr4) ^ H4) & (~0u << (8 * (i1 & 3))));
+            for (int it = 1; it < trips; ++it) {
+                const uint32_t g5 = ge_flags(r5[it], cthr4);
+                const uint32_t g3 = ge_flags(r3[it], cthr4) ^ H4;
+                const uint32_t rel = 32u * (uint32_t)it; // wave-uniform
+                h5 = min(h5, __builtin_elementwise_add_sat(ffbl_or_none(g5), rel));
+                h3 = min(h3, __builtin_elementwise_add_sat(ffbl_or_none(g3), rel));
             }
-            if (have5 && h5 != NONE) five = (int)(h5 >> 3);
-            if (done && h3 != NONE) three = (int)(h3 >> 3);
+            if (have5 && h5 != NONE) five = 4 * k5 + (int)(h5 >> 3);
+            if (done && h3 != NONE) three = 4 * k3 + (int)(h3 >> 3);
         }
 
         // ---- range error: only if the first bad char is one the reference would have read

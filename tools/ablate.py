@@ -27,6 +27,8 @@ NAMES = {0: "2buf mfma full", 1: "2buf dma-only", 2: "2buf mfma scan-only", 10: 
 CONFIGS = [(8, (0, 1, 2, 10, 12)), (16, (100, 101, 102, 110)), (12, (100,)), (8, (100,)), (6, (0,))]
 if os.environ.get("SK_ABLATE_SHORT"):
     CONFIGS = [(16, (100, 101, 102)), (8, (0, 1))]
+if os.environ.get("SK_ABLATE_AB"):
+    CONFIGS = [(16, (100,)), (8, (0,)), (16, (100,)), (8, (0,)), (16, (100,)), (8, (0,)), (16, (101,)), (8, (1,)), (16, (102,)), (8, (2,))]
 for per_cu, modes in CONFIGS:
     for mode in modes:
         ts = []
