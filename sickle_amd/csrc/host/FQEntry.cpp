@@ -17,6 +17,20 @@ FQEntry::FQEntry(int previous, Batch *reader)
     validate();
 }
 
+FQEntry::FQEntry(const Batch &batch, size_t first_line, int position_) : position(position_)
+{
+    name = batch.line(first_line);
+    seq = batch.line(first_line + 1);
+    comment = batch.line(first_line + 2);
+    qual = batch.line(first_line + 3);
+}
+
+bool FQEntry::well_formed() const
+{
+    return name.length() > 1 && name[0] == '@' && seq.length() >= 1 && qual.length() >= 1 &&
+           qual.length() == seq.length();
+}
+
 // reference src/FQEntry.cpp:53-97
 void FQEntry::validate() const
 {

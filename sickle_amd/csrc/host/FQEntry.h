@@ -13,6 +13,9 @@ public:
     FQEntry() : position(0) {}
     // takes the next four lines of the batch; `previous` = position of the record before it
     FQEntry(int previous, Batch *reader);
+    // the record at lines first_line..first_line+3 of the batch, NOT validated (parallel framing)
+    FQEntry(const Batch &batch, size_t first_line, int position_);
+    bool well_formed() const; // the checks of validate(), silently
     std::string_view name;
     std::string_view comment;
     std::string_view seq;

@@ -1,117 +1,177 @@
 #include "GZReader.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
-#include <iostream>
 
+#include "WorkerPool.h"
 #include "sickle.h"
 
 namespace {
-constexpr size_t kBlock = 8u << 20; // bytes per gzread
+constexpr size_t kBlock = 32u << 20; // bytes per read
 }
 
 GZReader::GZReader(const char *path_, int batch_len_, bool interleaved) : path(path_), batch_len(batch_len_)
 {
     min_lines_in_batch = interleaved ? 8 : 4; // reference src/GZReader.cpp:7-11
-    file = gzopen(path, "r");
-    if (!file) {
+    fd = open(path, O_RDONLY);
+    if (fd < 0) {
         fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path); // src/GZReader.cpp:15
         eof = true;
         return;
     }
-    gzbuffer(file, 1u << 20);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = pread(fd, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { // gzip: hand the descriptor to zlib
+        file = gzdopen(fd, "r");
+        fd = -1;
+        if (!file) {
+            fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path);
+            eof = true;
+            return;
+        }
+        gzbuffer(file, 4u << 20);
+    } else {
+        posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    }
 }
 
 GZReader::~GZReader()
 {
     if (file) gzclose(file);
+    if (fd >= 0) close(fd);
 }
 
 bool GZReader::fill()
 {
-    if (in_eof || !file) return false;
+    if (in_eof) return false;
     const size_t old = pending.size();
-    pending.resize(old + kBlock);
-    int got = gzread(file, pending.data() + old, (unsigned)kBlock);
-    if (got < 0) got = 0;
-    pending.resize(old + (size_t)got);
-    if ((size_t)got < kBlock) in_eof = true;
+    pending.reserve(old + kBlock);
+    size_t got = 0;
+    if (file) {
+        const int r = gzread(file, pending.data() + old, (unsigned)kBlock);
+        got = r > 0 ? (size_t)r : 0;
+        if (got < kBlock) in_eof = true;
+    } else {
+        while (got < kBlock) { // read(2) may return short counts
+            const ssize_t r = read(fd, pending.data() + old + got, kBlock - got);
+            if (r <= 0) {
+                in_eof = true;
+                break;
+            }
+            got += (size_t)r;
+        }
+    }
+    pending.set_size(old + got);
     return got > 0;
 }
 
-// What one gzgets(file, buf, batch_len) call would return: up to batch_len-1 characters, ending
-// after the first newline.  False at end of input.
-bool GZReader::next_piece(size_t *start, size_t *len)
+// Cuts [indexed, pending.size()) into lines: every newline ends one; at end of input the
+// unterminated tail is a line too.  The newline search runs on all host threads.
+void GZReader::index_more()
 {
-    const size_t limit = (size_t)(batch_len > 1 ? batch_len - 1 : 1);
-    for (;;) {
-        const size_t avail = pending.size() - scan;
-        const size_t look = avail < limit ? avail : limit;
-        const char *base = pending.data() + scan;
-        const char *nl = look ? (const char *)memchr(base, '\n', look) : nullptr;
-        if (nl) {
-            *start = scan;
-            *len = (size_t)(nl - base) + 1;
-            scan += *len;
-            return true;
+    const char *base = pending.data();
+    const size_t begin = indexed, end = pending.size();
+    if (begin >= end) return;
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t span = end - begin;
+    size_t parts = span / (2u << 20);
+    if (parts < 1) parts = 1;
+    if (parts > (size_t)pool.size() * 2) parts = (size_t)pool.size() * 2;
+    std::vector<std::vector<uint64_t>> found(parts);
+    pool.parallel_for(span, parts, [&](size_t b, size_t e, size_t part) {
+        std::vector<uint64_t> &out = found[part];
+        out.reserve((e - b) / 64 + 16);
+        const char *p = base + begin + b, *stop = base + begin + e;
+        while (p < stop) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(stop - p));
+            if (!nl) break;
+            out.push_back((uint64_t)(nl - base));
+            p = nl + 1;
         }
-        if (look == limit) { // a piece cut by the buffer size, no newline in it
-            *start = scan;
-            *len = limit;
-            scan += limit;
-            return true;
+    });
+    size_t start = begin;
+    for (const std::vector<uint64_t> &v : found)
+        for (uint64_t nl : v) {
+            idx_off.push_back(start);
+            idx_bytes.push_back((uint32_t)(nl + 1 - start));
+            start = nl + 1;
         }
-        if (!fill()) {
-            if (avail == 0) return false;
-            *start = scan; // the last line of a file that does not end in a newline
-            *len = avail;
-            scan += avail;
-            return true;
-        }
+    if (in_eof && start < end) { // the last line of a file that does not end in a newline
+        idx_off.push_back(start);
+        idx_bytes.push_back((uint32_t)(end - start));
+        start = end;
     }
+    indexed = start;
 }
 
 Batch *GZReader::get_batch_buffering_lines()
 {
     if (eof) return nullptr; // src/GZReader.cpp:31
-    Batch *batch = new Batch();
-    std::vector<uint64_t> &off = batch->line_off;
-    std::vector<uint32_t> &len = batch->line_len;
+    // gzgets(file, buf, batch_len) hands out at most batch_len-1 characters per call: a longer
+    // line arrives in pieces, each stored minus its last character
+    const uint32_t limit = (uint32_t)(batch_len > 1 ? batch_len - 1 : 1);
     long remaining = batch_len; // src/GZReader.cpp:61
-    off = carry_off;
-    len = carry_len;
-    for (uint32_t l : len) remaining -= l; // src/GZReader.cpp:68-75
-    carry_off.clear();
-    carry_len.clear();
+    size_t k = 0;               // lines of idx_* taken into this batch
+    for (; k < n_carry; ++k) remaining -= (long)(idx_bytes[k] - 1); // src/GZReader.cpp:68-75
     do {
-        size_t start, plen;
-        if (!next_piece(&start, &plen)) { // src/GZReader.cpp:77-80
-            eof = true;
-            break;
+        if (k == idx_off.size()) { // out of indexed lines: index what is buffered, else read on
+            index_more();
+            if (k == idx_off.size()) {
+                const bool got = fill();
+                index_more(); // at end of input this also takes an unterminated last line
+                if (k == idx_off.size()) {
+                    if (!got) { // src/GZReader.cpp:77-80: gzgets returned NULL
+                        eof = true;
+                        break;
+                    }
+                    continue; // a whole block without a newline: keep reading
+                }
+            }
         }
-        const size_t stored = plen - 1; // the piece minus its last character, src/GZReader.cpp:81-88
-        remaining -= (long)stored;
-        off.push_back(start);
-        len.push_back((uint32_t)stored);
+        if (idx_bytes[k] > limit) { // split off the first piece of an over-long line
+            idx_off.insert(idx_off.begin() + (long)k + 1, idx_off[k] + limit);
+            idx_bytes.insert(idx_bytes.begin() + (long)k + 1, idx_bytes[k] - limit);
+            idx_bytes[k] = limit;
+        }
+        remaining -= (long)(idx_bytes[k] - 1); // the piece minus its last character, src/GZReader.cpp:81-88
+        ++k;
     } while (remaining > 0);
 
     // src/GZReader.cpp:104-129: the trailing lines that do not complete a record are carried
-    const size_t extra = len.size() % (size_t)min_lines_in_batch;
-    const size_t keep = len.size() - extra;
-    // everything from the first carried line (or from `scan`) on stays in `pending`
-    const size_t cut = extra ? (size_t)off[keep] : scan;
-    std::vector<char> rest(pending.begin() + (long)cut, pending.end());
-    for (size_t i = keep; i < len.size(); ++i) {
-        carry_off.push_back(off[i] - cut);
-        carry_len.push_back(len[i]);
+    const size_t extra = k % (size_t)min_lines_in_batch;
+    const size_t keep = k - extra;
+    Batch *batch = new Batch();
+    batch->line_off.assign(idx_off.begin(), idx_off.begin() + (long)keep);
+    batch->line_len.resize(keep);
+    long total = 0;
+    for (size_t i = 0; i < keep; ++i) {
+        batch->line_len[i] = idx_bytes[i] - 1;
+        total += idx_bytes[i] - 1;
     }
-    off.resize(keep);
-    len.resize(keep);
-    pending.resize(cut);
+    batch->sequences_len = total;
+
+    // everything from the first carried line on stays in `pending` for the next batch
+    const size_t cut = keep < idx_off.size() ? (size_t)idx_off[keep] : indexed;
+    RawBuf rest;
+    const size_t rest_bytes = pending.size() - cut;
+    rest.reserve(rest_bytes + 1);
+    memcpy(rest.data(), pending.data() + cut, rest_bytes);
+    rest.set_size(rest_bytes);
+    pending.set_size(cut);
     batch->text.swap(pending);
     pending.swap(rest);
-    scan -= cut;
-    for (uint32_t l : len) batch->sequences_len += l;
+    const size_t left = idx_off.size() - keep;
+    for (size_t i = 0; i < left; ++i) {
+        idx_off[i] = idx_off[keep + i] - cut;
+        idx_bytes[i] = idx_bytes[keep + i];
+    }
+    idx_off.resize(left);
+    idx_bytes.resize(left);
+    indexed -= cut;
+    n_carry = extra;
     if (keep == 0) { // src/GZReader.cpp:33-40
         delete batch;
         return nullptr;

@@ -1,9 +1,10 @@
 // GZReader.h -- FASTQ ingest: (optionally gzipped) file -> batches of lines.
 //
 // Role of reference src/GZReader.{h,cpp} and src/Batch.{h,cpp}; written fresh.  The reference
-// reads line by line with gzgets into one heap string per line; this reader pulls megabyte
-// blocks with gzread straight into the batch's own text buffer and indexes the lines in
-// place.  What it keeps is the reference's BATCH CUT RULE, because that rule is observable:
+// reads line by line with gzgets into one heap string per line; this reader pulls large blocks
+// (read(2) for plain files, gzread for gzip) straight into the batch's own text buffer, finds
+// the newlines of a block with all host threads at once, and indexes the lines in place.  What
+// it keeps is the reference's BATCH CUT RULE, because that rule is observable:
 //   - a batch ends after the line that drives the byte budget to <= 0 (src/GZReader.cpp:61-92),
 //     the budget being batch_len minus the carried lines;
 //   - the trailing (lines mod 4) lines -- mod 8 for interleaved input -- are carried into the
@@ -21,8 +22,42 @@
 #include <zlib.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string_view>
 #include <vector>
+
+// growable byte buffer without value-initialisation (a std::vector<char> would zero every block
+// before read() overwrites it)
+class RawBuf {
+public:
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    void reserve(size_t c)
+    {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : (1u << 20);
+        while (nc < c) nc += nc >> 1;
+        p = (char *)realloc(p, nc);
+        if (!p) abort();
+        cap = nc;
+    }
+    void set_size(size_t s) { n = s; }
+    void swap(RawBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap, o.cap);
+    }
+
+private:
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+};
 
 // One batch: the text of its lines and where each line sits.  Role of reference src/Batch.h.
 class Batch {
@@ -36,12 +71,14 @@ public:
     }
     std::string_view line(size_t i) const { return std::string_view(text.data() + line_off[i], line_len[i]); }
     int n_lines() const { return (int)line_len.size(); }
+    size_t cursor_pos() const { return cursor; }
+    void skip_lines(size_t k) { cursor += k; }
     long sequences_len = 0; // sum of the line lengths, as reference src/Batch.cpp:15
     void free_this() {}     // storage is owned by the object; kept for source compatibility
 
 private:
     friend class GZReader;
-    std::vector<char> text;
+    RawBuf text;
     std::vector<uint64_t> line_off;
     std::vector<uint32_t> line_len;
     size_t cursor = 0;
@@ -51,27 +88,30 @@ class GZReader {
 public:
     GZReader(const char *path, int batch_len, bool interleaved = false);
     ~GZReader();
-    bool is_open() const { return file != nullptr; }
+    bool is_open() const { return file != nullptr || fd >= 0; }
     // the next batch, or NULL when the run is over (see the cut rule above); caller deletes
     Batch *get_batch_buffering_lines();
     bool reached_end() const { return eof; }
     const char *path;
 
 private:
-    bool fill();                            // gzread another block behind `pending`
-    bool next_piece(size_t *start, size_t *len); // one gzgets-equivalent piece inside `pending`
+    bool fill();        // read another block behind `pending`
+    void index_more();  // find the newlines of the bytes not yet indexed
 
-    gzFile file = nullptr;
-    bool eof = false;    // gzgets would have returned NULL: no further batch
-    bool in_eof = false; // the underlying stream is exhausted
+    gzFile file = nullptr; // gzip input
+    int fd = -1;           // plain input: read(2), no zlib copy
+    bool eof = false;      // gzgets would have returned NULL: no further batch
+    bool in_eof = false;   // the underlying stream is exhausted
     int batch_len;
     int min_lines_in_batch;
-    // bytes read from the file and not yet handed out in a batch: first the carried lines
-    // (already indexed in carry_off/len, relative to pending), then unparsed bytes from `scan`
-    std::vector<char> pending;
-    size_t scan = 0;
-    std::vector<uint64_t> carry_off;
-    std::vector<uint32_t> carry_len;
+    // Bytes read from the file and not yet handed out in a batch.  [0, indexed) is cut into
+    // lines (idx_off / idx_bytes, bytes INCLUDING the terminating character that is not stored);
+    // the first n_carry of them were carried over from the previous batch.
+    RawBuf pending;
+    size_t indexed = 0;
+    std::vector<uint64_t> idx_off;
+    std::vector<uint32_t> idx_bytes;
+    size_t n_carry = 0;
 };
 
 #endif

@@ -1,5 +1,7 @@
 #include "trim.h"
 
+#include "WorkerPool.h"
+
 #include <sys/stat.h>
 
 #include <cstdlib>
@@ -153,23 +155,31 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
 
     sk_batch b;
     memset(&b, 0, sizeof b);
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = (size_t)pool.size() * 4;
     if (uniform) {
-        for (size_t i = 0; i < n; ++i) {
-            memcpy(s.qual + i * stride, reads[i].qual.data(), len0);
-            if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), len0);
-        }
+        pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; ++i) {
+                memcpy(s.qual + i * stride, reads[i].qual.data(), len0);
+                if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), len0);
+            }
+        });
         b.stride = (uint32_t)stride;
         b.read_len = (uint32_t)len0;
     } else {
         size_t at = 0;
         for (size_t i = 0; i < n; ++i) {
-            const size_t l = reads[i].qual.length();
             s.offsets[i] = at;
-            memcpy(s.qual + at, reads[i].qual.data(), l);
-            if (need_seq) memcpy(s.seq + at, reads[i].seq.data(), l);
-            at += l;
+            at += reads[i].qual.length();
         }
         s.offsets[n] = at;
+        pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; ++i) {
+                const size_t l = reads[i].qual.length();
+                memcpy(s.qual + s.offsets[i], reads[i].qual.data(), l);
+                if (need_seq) memcpy(s.seq + s.offsets[i], reads[i].seq.data(), l);
+            }
+        });
         b.offsets = s.offsets;
     }
     b.qual = s.qual;
@@ -206,6 +216,18 @@ const cutsites *Abstract_Trimmer::wait_scan(int slot, const std::vector<FQEntry>
         exit(EXIT_FAILURE);
     }
     return reinterpret_cast<const cutsites *>(slots[slot].cuts);
+}
+
+std::thread Abstract_Trimmer::prefetch_batches(GZReader *reader, Channel<Batch *> &out)
+{
+    return std::thread([reader, &out] {
+        for (;;) {
+            Batch *b = reader->get_batch_buffering_lines();
+            out.push(b);
+            if (!b) break;
+        }
+        out.close();
+    });
 }
 
 void Abstract_Trimmer::append_record(std::string &out, const FQEntry &read, const cutsites &cs)

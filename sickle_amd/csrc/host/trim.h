@@ -19,6 +19,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "FQEntry.h"
@@ -123,6 +124,18 @@ protected:
     // (src/trim.cpp:130-135) and exits 1.  The cut array stays valid until the slot is reused.
     const cutsites *wait_scan(int slot, const std::vector<FQEntry> &reads);
 
+    // Frames records [0, n) of a batch on all host threads: record i is made from the four lines
+    // starting at line first_line(i) with position position(i).  If any record is malformed the
+    // FIRST one in order is re-validated on the calling thread, which prints the reference's
+    // messages and exits (src/FQEntry.cpp:53-97).
+    template <typename LineOf, typename PosOf>
+    static void frame_records(std::vector<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
+                              PosOf position, size_t dst0 = 0, size_t dst_step = 1);
+
+    // Runs reader->get_batch_buffering_lines() ahead of the consumer on its own thread: batches
+    // arrive in order through `out`, a NULL marks the end (the reference's NULL return).
+    static std::thread prefetch_batches(GZReader *reader, Channel<Batch *> &out);
+
     // name\n seq[five,three)\n comment\n qual[five,three)\n  (src/trim_single.cpp:393-396)
     static void append_record(std::string &out, const FQEntry &read, const cutsites &cs);
 
@@ -157,5 +170,28 @@ private:
     Slot slots[kSlots];
     void grow(Slot &s, size_t bytes, size_t reads, bool need_seq);
 };
+
+#include "WorkerPool.h"
+
+template <typename LineOf, typename PosOf>
+void Abstract_Trimmer::frame_records(std::vector<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
+                                     PosOf position, size_t dst0, size_t dst_step)
+{
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = (size_t)pool.size() * 4;
+    std::vector<size_t> first_bad(parts, (size_t)-1);
+    pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t part) {
+        for (size_t i = lo; i < hi; ++i) {
+            FQEntry &e = reads[dst0 + i * dst_step];
+            e = FQEntry(batch, first_line(i), position(i));
+            if (!e.well_formed() && first_bad[part] == (size_t)-1) first_bad[part] = i;
+        }
+    });
+    for (size_t part = 0; part < parts; ++part)
+        if (first_bad[part] != (size_t)-1) {
+            reads[dst0 + first_bad[part] * dst_step].validate(); // prints and exits
+            break;
+        }
+}
 
 #endif

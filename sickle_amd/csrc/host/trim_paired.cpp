@@ -2,6 +2,7 @@
 
 #include <getopt.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -244,35 +245,64 @@ void Trim_Paired::close_streams()
 // written one after the other (:388-403, :530-533), so -a T > 1 gives queue-major file order.
 void Trim_Paired::output_paired(Work &w)
 {
-    int b_kept_p = 0, b_kept_s1 = 0, b_kept_s2 = 0, b_discard_p = 0, b_discard_s1 = 0, b_discard_s2 = 0;
-    std::string fq1, fq2, singles;
     const size_t pairs = w.reads.size() / 2;
     const size_t T = (size_t)threads;
-    for (size_t q = 0; q < T; ++q) {
-        for (size_t k = q; k < pairs; k += T) {
+    // queue q holds pairs k = q, q+T, ...; start[q] = output index of its first
+    std::vector<size_t> start(T + 1, 0);
+    for (size_t q = 0; q < T; ++q) start[q + 1] = start[q] + (q < pairs ? (pairs - q + T - 1) / T : 0);
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = std::min<size_t>((size_t)pool.size() * 2, pairs ? pairs : 1);
+    struct Part {
+        std::string fq1, fq2, singles;
+        int kept_p = 0, kept_s1 = 0, kept_s2 = 0, discard_p = 0, discard_s1 = 0, discard_s2 = 0;
+    };
+    std::vector<Part> part_out(parts);
+    const bool inter = input_inter != nullptr;
+    pool.parallel_for(pairs, parts, [&](size_t lo, size_t hi, size_t part) {
+        Part &o = part_out[part];
+        size_t q = 0;
+        while (start[q + 1] <= lo) ++q;
+        size_t k = q + (lo - start[q]) * T;
+        // reservation: a stretch keeps most of its bytes; sized from its first pair
+        const FQEntry &f = w.reads[2 * k];
+        const size_t approx = (hi - lo) * (f.name.size() + f.comment.size() + 2 * f.seq.size() + 8);
+        o.fq1.reserve(inter ? 2 * approx : approx);
+        if (!inter) o.fq2.reserve(approx);
+        for (size_t j = lo; j < hi; ++j) {
             const FQEntry &read1 = w.reads[2 * k], &read2 = w.reads[2 * k + 1];
             const cutsites &cs1 = w.cuts[2 * k], &cs2 = w.cuts[2 * k + 1];
             const bool r1 = cs1.three_prime_cut >= 0; // src/trim_paired.cpp:500,502
             const bool r2 = cs2.three_prime_cut >= 0;
             if (r1 && r2) {
-                append_record(fq1, read1, cs1);
-                if (input_inter) append_record(fq1, read2, cs2);
-                else append_record(fq2, read2, cs2);
-                b_kept_p += 2;
+                append_record(o.fq1, read1, cs1);
+                if (inter) append_record(o.fq1, read2, cs2);
+                else append_record(o.fq2, read2, cs2);
+                o.kept_p += 2;
             } else if (r1 || r2) {
                 if (r1) {
-                    append_record(singles, read1, cs1);
-                    b_kept_s1++;
-                    b_discard_s2++;
+                    append_record(o.singles, read1, cs1);
+                    o.kept_s1++;
+                    o.discard_s2++;
                 } else {
-                    append_record(singles, read2, cs2);
-                    b_kept_s2++;
-                    b_discard_s1++;
+                    append_record(o.singles, read2, cs2);
+                    o.kept_s2++;
+                    o.discard_s1++;
                 }
             } else {
-                b_discard_p += 2;
+                o.discard_p += 2;
             }
+            k += T;
+            if (k >= pairs && j + 1 < hi) { ++q; while (start[q + 1] == start[q]) ++q; k = q; }
         }
+    });
+    int b_kept_p = 0, b_kept_s1 = 0, b_kept_s2 = 0, b_discard_p = 0, b_discard_s1 = 0, b_discard_s2 = 0;
+    for (const Part &o : part_out) {
+        b_kept_p += o.kept_p;
+        b_kept_s1 += o.kept_s1;
+        b_kept_s2 += o.kept_s2;
+        b_discard_p += o.discard_p;
+        b_discard_s1 += o.discard_s1;
+        b_discard_s2 += o.discard_s2;
     }
     kept_p += b_kept_p;
     kept_s1 += b_kept_s1;
@@ -284,14 +314,16 @@ void Trim_Paired::output_paired(Work &w)
     // so the summary's "Total input FastQ records" is the size of the last batch written.
     total = b_kept_p + b_kept_s1 + b_kept_s2 + b_discard_p + b_discard_s1 + b_discard_s2;
 
-    if (input_inter) {
-        outfile_interleaved.write(fq1);
-        if (sfn) outfile_single.write(singles);
-    } else {
-        outfile.write(fq1);
-        outfile2.write(fq2);
-        if (sfn) outfile_single.write(singles);
-    }
+    // the output files are independent: write them side by side
+    std::thread t2, t3;
+    if (!inter)
+        t2 = std::thread([&] { for (const Part &o : part_out) outfile2.write(o.fq2); });
+    if (sfn)
+        t3 = std::thread([&] { for (const Part &o : part_out) outfile_single.write(o.singles); });
+    OutFile &first = inter ? outfile_interleaved : outfile;
+    for (const Part &o : part_out) first.write(o.fq1);
+    if (t2.joinable()) t2.join();
+    if (t3.joinable()) t3.join();
     delete w.batch;
     delete w.batch2;
     w.batch = w.batch2 = nullptr;
@@ -306,15 +338,19 @@ int Trim_Paired::trim_main()
 
     Channel<Work *> parsed(2), scanned(2);
     StageClock clk_read, clk_frame, clk_pack, clk_wait, clk_out;
+    // each input file is read and indexed ahead on its own thread
+    Channel<Batch *> raw1(1), raw2(1);
+    std::thread fetch1 = prefetch_batches(input, raw1), fetch2;
+    if (!input_inter) fetch2 = prefetch_batches(input2, raw2);
     std::thread reader([&] {
         // the batch loop of reference src/trim_paired.cpp:280-453, minus the worker threads
         while (true) {
             StageClock::Scope rd(clk_read);
-            Batch *batch = input->get_batch_buffering_lines();
-            if (batch == NULL) break;
+            Batch *batch = NULL;
+            if (!raw1.pop(batch) || batch == NULL) break;
             Batch *batch2 = NULL;
             if (!input_inter) {
-                batch2 = input2->get_batch_buffering_lines();
+                if (!raw2.pop(batch2)) batch2 = NULL;
                 if (batch2 == NULL) {
                     delete batch;
                     break;
@@ -331,26 +367,50 @@ int Trim_Paired::trim_main()
             Work *w = new Work();
             w->batch = batch;
             w->batch2 = batch2;
-            w->reads.reserve((size_t)batch->n_lines() / (input_inter ? 4 : 2));
+            // :350-404 -- pairs are framed until the batch ends or until the running sum of mate-1
+            // lengths passes batch_len (the check sits BEFORE each pair, :352-358); what is left
+            // of the batch after that is dropped
+            const size_t lines_per_pair = input_inter ? 8 : 4;
+            const size_t all_pairs = (size_t)batch->n_lines() / lines_per_pair;
+            size_t pairs = 0;
             int chars_read_from_batch = 0;
-            int last_read_position = 0, last_read_position2 = 0; // per batch in PE (:309-310)
-            while (batch->has_lines()) {
-                if (chars_read_from_batch > batch_len) break; // :352-358
-                w->reads.emplace_back(last_read_position, batch);
-                last_read_position = w->reads.back().position;
-                const int read_len = (int)w->reads.back().seq.length();
-                if (input_inter && !batch->has_lines()) {
-                    error("Reading interleaved pair: read1 loaded, but no read2 to load. Maybe it's not an interleaved file?");
-                    exit(EXIT_FAILURE);
-                }
-                if (input_inter) {
-                    w->reads.emplace_back(last_read_position, batch);
-                    last_read_position = w->reads.back().position;
-                } else {
-                    w->reads.emplace_back(last_read_position2, batch2);
-                    last_read_position2 = w->reads.back().position;
-                }
-                chars_read_from_batch += read_len;
+            while (pairs < all_pairs) {
+                if (chars_read_from_batch > batch_len) break;
+                chars_read_from_batch += (int)batch->line(pairs * lines_per_pair + 1).length();
+                ++pairs;
+            }
+            if (input_inter && pairs == all_pairs && (size_t)batch->n_lines() % 8 == 4) {
+                // unreachable (interleaved batches hold whole pairs), kept for the message
+                error("Reading interleaved pair: read1 loaded, but no read2 to load. Maybe it's not an interleaved file?");
+                exit(EXIT_FAILURE);
+            }
+            w->reads.resize(2 * pairs);
+            // record positions restart at 1 in every batch in PE (:309-310)
+            if (input_inter) {
+                frame_records(w->reads, *batch, 2 * pairs, [](size_t i) { return 4 * i; },
+                              [](size_t i) { return (int)i + 1; });
+            } else {
+                // mate 1 first, then mate 2: a malformed mate 1 anywhere is reported before any
+                // mate 2 problem only if it comes first in the reference's own order, which
+                // alternates -- so check the pairs in that order afterwards
+                std::vector<FQEntry> &rd = w->reads;
+                WorkerPool &pool = WorkerPool::instance();
+                const size_t parts = (size_t)pool.size() * 4;
+                std::vector<size_t> first_bad(parts, (size_t)-1);
+                pool.parallel_for(pairs, parts, [&](size_t lo, size_t hi, size_t part) {
+                    for (size_t k = lo; k < hi; ++k) {
+                        rd[2 * k] = FQEntry(*batch, 4 * k, (int)k + 1);
+                        rd[2 * k + 1] = FQEntry(*batch2, 4 * k, (int)k + 1);
+                        if ((!rd[2 * k].well_formed() || !rd[2 * k + 1].well_formed()) && first_bad[part] == (size_t)-1)
+                            first_bad[part] = k;
+                    }
+                });
+                for (size_t part = 0; part < parts; ++part)
+                    if (first_bad[part] != (size_t)-1) {
+                        rd[2 * first_bad[part]].validate(); // prints and exits if mate 1 is the bad one
+                        rd[2 * first_bad[part] + 1].validate();
+                        break;
+                    }
             }
             if (chars_read_from_batch == 0) { // :407-409
                 delete batch;
@@ -362,6 +422,12 @@ int Trim_Paired::trim_main()
             parsed.push(w);
         }
         parsed.close();
+        // the run may end before the files do (different batch lengths, :335-338): drain the
+        // prefetchers so that they can finish
+        Batch *rest;
+        while (raw1.pop(rest)) delete rest;
+        if (!input_inter)
+            while (raw2.pop(rest)) delete rest;
     });
     std::thread writer([&] {
         Work *w;
@@ -400,6 +466,8 @@ int Trim_Paired::trim_main()
     for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
     scanned.close();
     reader.join();
+    fetch1.join();
+    if (fetch2.joinable()) fetch2.join();
     writer.join();
     StageClock::report({{"read+index", &clk_read}, {"frame", &clk_frame}, {"pack+submit", &clk_pack},
                         {"device wait", &clk_wait}, {"classify+write", &clk_out}});

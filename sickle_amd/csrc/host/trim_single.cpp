@@ -5,6 +5,7 @@
 #include <climits>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <thread>
 
@@ -171,23 +172,55 @@ void Trim_Single::close_streams()
 // -a T > 1 the records of a batch come out queue-major.  Reproduced, since it is the file order.
 void Trim_Single::output_single(Work &w)
 {
-    std::string to_print;
     const size_t n = w.reads.size();
-    to_print.reserve((size_t)w.batch->sequences_len + 4 * n);
     const size_t T = (size_t)threads;
+    // queue q holds reads k = (q + T - 1) % T, +T, +2T, ...; start[q] = output index of its first
+    std::vector<size_t> start(T + 1, 0);
     for (size_t q = 0; q < T; ++q) {
-        for (size_t k = (q + T - 1) % T; k < n; k += T) {
+        const size_t k0 = (q + T - 1) % T;
+        start[q + 1] = start[q] + (k0 < n ? (n - k0 + T - 1) / T : 0);
+    }
+    // every host thread assembles a contiguous stretch of the OUTPUT order into its own buffer
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = std::min<size_t>((size_t)pool.size() * 2, n ? n : 1);
+    std::vector<std::string> text(parts);
+    std::vector<int> part_kept(parts, 0), part_discard(parts, 0);
+    pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t part) {
+        std::string &out = text[part];
+        size_t bytes = 0;
+        size_t q = 0;
+        while (start[q + 1] <= lo) ++q;
+        size_t k = (q + T - 1) % T + (lo - start[q]) * T;
+        for (size_t j = lo; j < hi; ++j) { // size pass: reserve once
+            const cutsites &cs = w.cuts[k];
+            if (cs.three_prime_cut >= 0)
+                bytes += w.reads[k].name.size() + w.reads[k].comment.size() + 4 +
+                         2 * (size_t)(cs.three_prime_cut - cs.five_prime_cut);
+            k += T;
+            if (k >= n && j + 1 < hi) { ++q; while (start[q + 1] == start[q]) ++q; k = (q + T - 1) % T; }
+        }
+        out.reserve(bytes);
+        q = 0;
+        while (start[q + 1] <= lo) ++q;
+        k = (q + T - 1) % T + (lo - start[q]) * T;
+        for (size_t j = lo; j < hi; ++j) {
             const cutsites &cs = w.cuts[k];
             if (!(cs.three_prime_cut >= 0)) { // src/trim_single.cpp:368
-                discard++;
+                part_discard[part]++;
             } else {
-                append_record(to_print, w.reads[k], cs);
-                kept++;
+                append_record(out, w.reads[k], cs);
+                part_kept[part]++;
             }
+            k += T;
+            if (k >= n && j + 1 < hi) { ++q; while (start[q + 1] == start[q]) ++q; k = (q + T - 1) % T; }
         }
+    });
+    for (size_t part = 0; part < parts; ++part) {
+        kept += part_kept[part];
+        discard += part_discard[part];
+        outfile.write(text[part]);
     }
     total = kept + discard;
-    outfile.write(to_print);
     delete w.batch;
     w.batch = nullptr;
 }
@@ -203,16 +236,20 @@ int Trim_Single::trim_main()
     // ingest thread -> (this thread: device) -> output thread; two batches in flight on the
     // device so that the H2D copy of one overlaps the scan of the other
     Channel<Work *> parsed(2), scanned(2);
+    Channel<Batch *> raw(1);
+    std::thread fetcher = prefetch_batches(input, raw);
     std::thread reader([&] {
         int last_read_position = 0; // counts across batches in SE (src/trim_single.cpp:238)
-        while (Batch *batch = input->get_batch_buffering_lines()) {
+        Batch *batch;
+        while (raw.pop(batch) && batch) {
             Work *w = new Work();
             w->batch = batch;
-            w->reads.reserve((size_t)batch->n_lines() / 4);
-            while (batch->has_lines()) {
-                w->reads.emplace_back(last_read_position, batch); // validates, exits on a bad record
-                last_read_position = w->reads.back().position;
-            }
+            const size_t n = (size_t)batch->n_lines() / 4;
+            w->reads.resize(n);
+            const int base = last_read_position;
+            frame_records(w->reads, *batch, n, [](size_t i) { return 4 * i; },
+                          [base](size_t i) { return base + (int)i + 1; });
+            last_read_position += (int)n;
             parsed.push(w);
         }
         parsed.close();
@@ -246,6 +283,7 @@ int Trim_Single::trim_main()
     for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
     scanned.close();
     reader.join();
+    fetcher.join();
     writer.join();
 
     if (!quiet)
