@@ -75,22 +75,37 @@ Abstract_Trimmer::~Abstract_Trimmer() { close_device(); }
 
 int Abstract_Trimmer::open_device()
 {
-    if (ctx) return 0;
-    int device = 0;
-    if (const char *e = getenv("SICKLE_DEVICE")) device = atoi(e);
-    const int rc = sk_create(device, kSlots, &ctx);
-    if (rc != SK_OK) {
-        // no CPU fallback: the scan exists only as HIP kernels for gfx950
-        fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
-                device, rc);
-        ctx = nullptr;
-        return EXIT_FAILURE;
-    }
+    if (ctx || device_opener.joinable()) return 0;
+    device_opener = std::thread([this] {
+        int device = 0;
+        if (const char *e = getenv("SICKLE_DEVICE")) device = atoi(e);
+        device_rc = sk_create(device, kSlots, &ctx);
+        if (device_rc != SK_OK) {
+            // no CPU fallback: the scan exists only as HIP kernels for gfx950
+            fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
+                    device, device_rc);
+            ctx = nullptr;
+            return;
+        }
+        // Pinned staging sized for a whole ingest batch, allocated here so that hipHostMalloc
+        // (slow, ~1 GB/s) also hides behind the first reads.  A batch holds at most ~batch_len
+        // bytes of text per input file; quality is under half of it.  Too small only means a
+        // later grow().
+        const size_t text = (size_t)batch_len * (size_t)staging_files;
+        for (Slot &s : slots) grow(s, text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0);
+    });
     return 0;
+}
+
+void Abstract_Trimmer::ensure_device()
+{
+    if (device_opener.joinable()) device_opener.join();
+    if (!ctx) exit(EXIT_FAILURE); // the opener has printed why
 }
 
 void Abstract_Trimmer::close_device()
 {
+    if (device_opener.joinable()) device_opener.join();
     if (!ctx) return;
     for (Slot &s : slots) {
         sk_host_free(ctx, s.qual);
@@ -135,6 +150,7 @@ void Abstract_Trimmer::grow(Slot &s, size_t bytes, size_t reads, bool need_seq)
 
 void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
 {
+    ensure_device();
     Slot &s = slots[slot];
     const size_t n = reads.size();
     // Layout: equal-length batches (the usual case) go at a fixed stride that is a multiple of 8

@@ -65,6 +65,18 @@ public:
         for (const auto &s : stages) fprintf(stderr, "[stage] %-16s %8.3f s\n", s.first, s.second->seconds);
     }
     double seconds = 0;
+    // timeline marks (seconds since the first mark), also under SICKLE_STAGE_TIMES=1
+    static void mark(const char *what)
+    {
+        static const bool on = [] {
+            const char *e = getenv("SICKLE_STAGE_TIMES");
+            return e && *e && *e != '0';
+        }();
+        if (!on) return;
+        static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mark] %7.3f s  %s\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
 };
 
 // bounded hand-off between pipeline stages
@@ -115,7 +127,11 @@ protected:
 
     // ---- the scan of one batch of reads on the device (what processing_thread did on CPU threads)
     static const int kSlots = 2;
-    int open_device(); // 0 ok; prints and returns EXIT_FAILURE without a usable gfx950 device
+    // Creates the device session on a helper thread (HIP start-up takes ~0.2 s, which the first
+    // batch's file reads hide); the first submit_scan waits for it and exits with the message
+    // below if there is no usable gfx950 device.  Always returns 0.
+    int open_device();
+    void require_device() { ensure_device(); }
     void close_device();
     // packs the quality (and, with -n, sequence) bytes of `reads` into the slot's pinned buffers
     // and enqueues H2D + scan + D2H; returns at once
@@ -157,6 +173,7 @@ protected:
     int kept;
     int discard;
     int total;
+    int staging_files = 1; // input files feeding one device batch (2 for two-file PE)
 
 private:
     struct Slot {
@@ -167,6 +184,9 @@ private:
         size_t cap_reads = 0;
     };
     sk_ctx *ctx = nullptr;
+    std::thread device_opener;
+    int device_rc = 0;
+    void ensure_device();
     Slot slots[kSlots];
     void grow(Slot &s, size_t bytes, size_t reads, bool need_seq);
 };

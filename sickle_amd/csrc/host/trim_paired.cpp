@@ -202,6 +202,7 @@ int Trim_Paired::init_streams()
             usage(EXIT_FAILURE, "****Error: The -f option cannot be used in combination with -c, -m, or -M.");
             return EXIT_FAILURE;
         }
+        staging_files = 2;
         input = new GZReader(infn, batch_len);
         if (!input->is_open()) return EXIT_FAILURE;
         input2 = new GZReader(infn2, batch_len);
@@ -333,8 +334,10 @@ int Trim_Paired::trim_main()
 {
     total = 0;
     kept_p = discard_p = kept_s1 = kept_s2 = discard_s1 = discard_s2 = 0;
+    StageClock::mark("trim_main");
     int res = init_streams();
     if (res != 0) return res;
+    StageClock::mark("streams + device open");
 
     Channel<Work *> parsed(2), scanned(2);
     StageClock clk_read, clk_frame, clk_pack, clk_wait, clk_out;
@@ -419,6 +422,7 @@ int Trim_Paired::trim_main()
                 break;
             }
             fr.stop();
+            StageClock::mark("batch framed");
             parsed.push(w);
         }
         parsed.close();
@@ -435,6 +439,7 @@ int Trim_Paired::trim_main()
             StageClock::Scope o(clk_out);
             output_paired(*w);
             delete w;
+            StageClock::mark("batch written");
         }
     });
 
@@ -460,10 +465,12 @@ int Trim_Paired::trim_main()
             StageClock::Scope pk(clk_pack);
             submit_scan(slot, w->reads);
         }
+        StageClock::mark("batch submitted");
         inflight[slot] = w;
         ++i;
     }
     for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    require_device(); // even an empty input does not succeed without the GPU
     scanned.close();
     reader.join();
     fetch1.join();
@@ -484,5 +491,6 @@ int Trim_Paired::trim_main()
         else fprintf(stdout, "FastQ single records discarded: %d (from PE1: %d, from PE2: %d)\n\n", (discard_s1 + discard_s2), discard_s1, discard_s2);
     }
     close_streams();
+    StageClock::mark("closed");
     return EXIT_SUCCESS;
 }

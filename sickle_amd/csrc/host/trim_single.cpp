@@ -281,6 +281,7 @@ int Trim_Single::trim_main()
         ++i;
     }
     for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    require_device(); // even an empty input does not succeed without the GPU
     scanned.close();
     reader.join();
     fetcher.join();
