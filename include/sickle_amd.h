@@ -113,7 +113,8 @@ void sk_host_free(sk_ctx *ctx, void *p);
 
 /*
  * Device-resident batch: every pointer in *batch and `out` is a DEVICE pointer.  Enqueues
- * the scan on `hip_stream` (a hipStream_t; NULL = the context's compute stream) and
+ * the scan on `hip_stream` (a hipStream_t; NULL = HIP's default stream, so it is ordered after
+ * the work the caller queued there) and
  * returns without waiting.  out[r] is written for every read.  Range errors of all scans
  * enqueued since the last sk_scan_device_finish accumulate in one device word (lowest read
  * index wins); nothing but the kernel is enqueued here.

@@ -338,14 +338,16 @@ int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *b
     sk_scan_args a;
     int rc = make_args(ctx, params, batch, &a);
     if (rc != SK_OK) return rc;
-    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->compute;
+    // NULL is HIP's default (null) stream, like everywhere else in HIP: ordered after whatever the
+    // caller queued there (e.g. the kernels that produced the batch)
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), ctx->d_err, stream);
 }
 
 int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err)
 {
     if (!ctx) return SK_EINVAL;
-    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->compute;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     SK_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     int rc = reset_error_word(ctx, ctx->d_err, stream);
     if (rc != SK_OK) return rc;

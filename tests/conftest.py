@@ -17,6 +17,10 @@ def pytest_configure(config):
 def sk_ctx():
     """One device context for the whole GPU session.  No skip, no fallback: without the
     in-tree libsickle_amd.so or without a gfx950 device the gpu tests FAIL."""
+    # torch first: its wheel bundles its own HIP runtime, and whichever copy of libamdhip64 a
+    # process loads first is the one every later library gets.  bench.py has the same order.
+    import torch
+    torch.cuda.is_available()
     from sickle_amd import capi
     ctx = capi.Context(device=0, slots=2)
     yield ctx
