@@ -135,7 +135,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     n, length = args.reads, args.len
-    stride = (length + 7) // 8 * 8
+    stride = (length + 7) // 8  # multiple of 8 with an odd number of 8-byte units: LDS-bank friendly rows
+    stride = (stride + (1 - stride % 2)) * 8
     qual = synth_quals_device(torch, n, length, stride, 1234 + rank, device)
     out = torch.empty((n, 2), dtype=torch.int32, device=device)
     ctx = capi.Context(device=local_rank, slots=1)

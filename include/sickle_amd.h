@@ -25,7 +25,8 @@
  *                 len_r = lengths ? lengths[r] : read_len.  The fast tiled kernel is used
  *                 when stride % 8 == 0 and stride <= SK_TILE_MAX_STRIDE and the base
  *                 pointers are 16-byte aligned; any other fixed-stride batch goes through
- *                 the general kernel.
+ *                 the general kernel.  Fastest when stride/8 is ODD (152, 104, 264 ...): the
+ *                 rows then spread over all LDS banks; stride/8 even still works, slower.
  * seq is only read when params->trunc_n != 0 (the N rule, src/trim.cpp:86-98) and may be
  * NULL otherwise.
  */

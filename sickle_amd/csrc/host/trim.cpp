@@ -153,19 +153,29 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     ensure_device();
     Slot &s = slots[slot];
     const size_t n = reads.size();
-    // Layout: equal-length batches (the usual case) go at a fixed stride that is a multiple of 8
-    // and take the tiled kernel; mixed lengths are packed back to back with an offsets array so
-    // that PCIe carries no padding.
-    size_t total_len = 0;
+    // Layout.  Equal-length batches (the usual case): fixed stride, uniform length -> the tiled
+    // kernel with the matrix-pipe window sums.  Mixed lengths up to SK_TILE_MAX_STRIDE: the same
+    // fixed stride (padded to the longest read) plus a per-read length array -> the tiled kernel's
+    // vector path, which is ~8x the rate of the general kernel; the padding only costs PCIe bytes,
+    // and PCIe is two orders of magnitude ahead of the host parser.  Anything longer: packed back
+    // to back with an offsets array -> the general (wave-per-read) kernel.
+    size_t total_len = 0, max_len = 0;
     bool uniform = true;
     const size_t len0 = n ? reads[0].qual.length() : 0;
     for (const FQEntry &r : reads) {
-        total_len += r.qual.length();
-        uniform = uniform && r.qual.length() == len0;
+        const size_t l = r.qual.length();
+        total_len += l;
+        if (l > max_len) max_len = l;
+        uniform = uniform && l == len0;
     }
-    uniform = uniform && len0 > 0 && ((len0 + 7) / 8 * 8) <= SK_TILE_MAX_STRIDE;
-    const size_t stride = uniform ? (len0 + 7) / 8 * 8 : 0;
-    const size_t bytes = uniform ? n * stride : total_len;
+    // stride: a multiple of 8 with an ODD number of 8-byte units, so that the per-lane row walks of
+    // the tiled kernel (ds_read_b64 at lane*stride) spread over all LDS banks; an even count
+    // (e.g. 250 -> 256) puts every lane on the same banks (measured: 2.6x slower)
+    size_t stride8 = (max_len + 7) / 8;
+    if (stride8 % 2 == 0) ++stride8;
+    const bool tiled = n > 0 && max_len > 0 && stride8 * 8 <= SK_TILE_MAX_STRIDE;
+    const size_t stride = tiled ? stride8 * 8 : 0;
+    const size_t bytes = tiled ? n * stride : total_len;
     const bool need_seq = trunc_n != 0;
     grow(s, bytes, n, need_seq);
 
@@ -173,15 +183,19 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     memset(&b, 0, sizeof b);
     WorkerPool &pool = WorkerPool::instance();
     const size_t parts = (size_t)pool.size() * 4;
-    if (uniform) {
+    if (tiled) {
+        uint32_t *lengths = reinterpret_cast<uint32_t *>(s.offsets); // the index buffer holds either
         pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
             for (size_t i = lo; i < hi; ++i) {
-                memcpy(s.qual + i * stride, reads[i].qual.data(), len0);
-                if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), len0);
+                const size_t l = reads[i].qual.length();
+                memcpy(s.qual + i * stride, reads[i].qual.data(), l);
+                if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), l);
+                if (!uniform) lengths[i] = (uint32_t)l;
             }
         });
         b.stride = (uint32_t)stride;
         b.read_len = (uint32_t)len0;
+        b.lengths = uniform ? nullptr : lengths;
     } else {
         size_t at = 0;
         for (size_t i = 0; i < n; ++i) {

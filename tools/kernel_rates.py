@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: HBM-resident rates of every kernel variant (not the bench metric)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from sickle_amd import capi
+
+dev = torch.device("cuda", 0)
+ctx = capi.Context(0, 1)
+s = torch.cuda.Stream(dev)
+
+
+def timeit(fn, reps=8):
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s); fn(); e1.record(s); s.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def report(name, ms, n, algo_bytes):
+    print("%-46s %8.3f ms  %7.2f G reads/s  %6.0f GB/s algorithmic" % (name, ms, n / ms / 1e6, algo_bytes / ms / 1e6), flush=True)
+
+
+n, L = 10_000_000, 150
+q = bench.synth_quals_device(torch, n, L, 152, 1, dev)
+seq = torch.full((n, 152), 65, dtype=torch.uint8, device=dev)
+seq[torch.rand(n, device=dev) < 0.25, 77] = ord("N")
+out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+p = capi.make_params("sanger", 20, 20)
+pn = capi.make_params("sanger", 20, 20, False, True)
+report("tile+mfma uniform 150 (stride 152)", timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=152, read_len=L, stream=s.cuda_stream)), n, n * 158)
+report("tile+mfma uniform 150, -n", timeit(lambda: ctx.scan_device_async(pn, q.data_ptr(), out.data_ptr(), n, stride=152, read_len=L, seq_ptr=seq.data_ptr(), stream=s.cuda_stream)), n, n * 308)
+lens = torch.full((n,), L, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+report("tile valu, per-read lengths (all 150)", timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=152, lengths_ptr=lens.data_ptr(), stream=s.cuda_stream)), n, n * 158)
+pk = q[:, :L].contiguous()
+off = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+torch.cuda.synchronize()
+report("wave kernel, ragged offsets (all 150)", timeit(lambda: ctx.scan_device_async(p, pk.data_ptr(), out.data_ptr(), n, offsets_ptr=off.data_ptr(), stream=s.cuda_stream), 3), n, n * 158)
+del pk, off, seq
+# mixed lengths 75..301
+m = 4_000_000
+q3 = bench.synth_quals_device(torch, m, 301, 304, 2, dev)
+lens3 = torch.randint(75, 302, (m,), device=dev, dtype=torch.int32)
+out3 = torch.empty((m, 2), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+tot = int(lens3.sum().item())
+report("tile valu, mixed 75-301 at stride 304", timeit(lambda: ctx.scan_device_async(p, q3.data_ptr(), out3.data_ptr(), m, stride=304, lengths_ptr=lens3.data_ptr(), stream=s.cuda_stream)), m, tot + 8 * m)
+q250 = bench.synth_quals_device(torch, m, 250, 264, 3, dev)
+torch.cuda.synchronize()
+report("tile+mfma uniform 250 (stride 264)", timeit(lambda: ctx.scan_device_async(p, q250.data_ptr(), out3.data_ptr(), m, stride=264, read_len=250, stream=s.cuda_stream)), m, m * 258)
+q100 = bench.synth_quals_device(torch, n, 100, 104, 3, dev)
+torch.cuda.synchronize()
+report("tile+mfma uniform 100 (stride 104)", timeit(lambda: ctx.scan_device_async(p, q100.data_ptr(), out.data_ptr(), n, stride=104, read_len=100, stream=s.cuda_stream)), n, n * 108)
+ctx.scan_device_finish(s.cuda_stream)
