@@ -127,19 +127,28 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the scan has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal knobs (never set by the driver): BENCH_FORCE_DEVICE puts every rank on one GPU and
+    # BENCH_DIST_BACKEND=gloo swaps RCCL for gloo, so that the N>1 code path can be exercised on a
+    # one-GPU box.
+    dev_index = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # backend "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+    reduce_device = device if backend == "nccl" else None
 
     n, length = args.reads, args.len
     stride = (length + 7) // 8  # multiple of 8 with an odd number of 8-byte units: LDS-bank friendly rows
     stride = (stride + (1 - stride % 2)) * 8
     qual = synth_quals_device(torch, n, length, stride, 1234 + rank, device)
     out = torch.empty((n, 2), dtype=torch.int32, device=device)
-    ctx = capi.Context(device=local_rank, slots=1)
+    ctx = capi.Context(device=dev_index, slots=1)
     params = capi.make_params("sanger", 20, 20)
     # A dedicated (non-default) stream: the C ABI takes the hipStream_t the kernel is launched on,
     # and the HIP events below are recorded on that same stream.
@@ -177,7 +186,7 @@ def main():
     bases_kept = int((out[:, 1] - out[:, 0]).clamp_(min=0).sum().item())
     # the only exchange: kept / discarded counters and the max elapsed, outside the timed region
     from sickle_amd.shard import reduce_counters
-    counts, elapsed = reduce_counters(dist, [kept, n - kept, bases_kept], elapsed, device)
+    counts, elapsed = reduce_counters(dist, [kept, n - kept, bases_kept], elapsed, reduce_device)
 
     res = None
     if rank == 0:
