@@ -75,24 +75,42 @@ Abstract_Trimmer::~Abstract_Trimmer() { close_device(); }
 
 int Abstract_Trimmer::open_device()
 {
-    if (ctx || device_opener.joinable()) return 0;
+    if (!device_ids.empty()) return 0;
+    // which GPUs: SICKLE_DEVICES=0,1,2 (several) or SICKLE_DEVICE=n (one), default device 0
+    if (const char *list = getenv("SICKLE_DEVICES")) {
+        for (const char *p = list; *p;) {
+            char *end;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            device_ids.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (device_ids.empty()) {
+        const char *e = getenv("SICKLE_DEVICE");
+        device_ids.push_back(e ? atoi(e) : 0);
+    }
+    ctxs.assign(device_ids.size(), nullptr);
+    slots.assign((size_t)n_slots(), Slot());
     device_opener = std::thread([this] {
-        int device = 0;
-        if (const char *e = getenv("SICKLE_DEVICE")) device = atoi(e);
-        device_rc = sk_create(device, kSlots, &ctx);
-        if (device_rc != SK_OK) {
-            // no CPU fallback: the scan exists only as HIP kernels for gfx950
-            fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
-                    device, device_rc);
-            ctx = nullptr;
-            return;
+        for (size_t g = 0; g < device_ids.size(); ++g) {
+            const int rc = sk_create(device_ids[g], kSlots, &ctxs[g]);
+            if (rc != SK_OK) {
+                // no CPU fallback: the scan exists only as HIP kernels for gfx950
+                fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
+                        device_ids[g], rc);
+                ctxs[g] = nullptr;
+                return;
+            }
         }
         // Pinned staging sized for a whole ingest batch, allocated here so that hipHostMalloc
         // (slow, ~1 GB/s) also hides behind the first reads.  A batch holds at most ~batch_len
         // bytes of text per input file; quality is under half of it.  Too small only means a
         // later grow().
         const size_t text = (size_t)batch_len * (size_t)staging_files;
-        for (Slot &s : slots) grow(s, text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0);
+        for (size_t i = 0; i < slots.size(); ++i)
+            grow(ctx_of((int)i), slots[i], text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0);
+        devices_ok = true;
     });
     return 0;
 }
@@ -100,25 +118,33 @@ int Abstract_Trimmer::open_device()
 void Abstract_Trimmer::ensure_device()
 {
     if (device_opener.joinable()) device_opener.join();
-    if (!ctx) exit(EXIT_FAILURE); // the opener has printed why
+    if (!devices_ok) exit(EXIT_FAILURE); // the opener has printed why
 }
 
 void Abstract_Trimmer::close_device()
 {
     if (device_opener.joinable()) device_opener.join();
-    if (!ctx) return;
-    for (Slot &s : slots) {
-        sk_host_free(ctx, s.qual);
-        sk_host_free(ctx, s.seq);
-        sk_host_free(ctx, s.offsets);
-        sk_host_free(ctx, s.cuts);
+    for (size_t i = 0; i < slots.size(); ++i) {
+        sk_ctx *c = ctxs[i % ctxs.size()];
+        if (!c) continue;
+        Slot &s = slots[i];
+        sk_host_free(c, s.qual);
+        sk_host_free(c, s.seq);
+        sk_host_free(c, s.offsets);
+        sk_host_free(c, s.cuts);
         s = Slot();
     }
-    sk_destroy(ctx);
-    ctx = nullptr;
+    for (sk_ctx *&c : ctxs) {
+        if (c) sk_destroy(c);
+        c = nullptr;
+    }
+    slots.clear();
+    ctxs.clear();
+    device_ids.clear();
+    devices_ok = false;
 }
 
-void Abstract_Trimmer::grow(Slot &s, size_t bytes, size_t reads, bool need_seq)
+void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq)
 {
     auto fail = [&](const char *what) {
         fprintf(stderr, "****Error: could not allocate pinned %s buffer: %s\n\n", what, sk_last_error(ctx));
@@ -151,7 +177,9 @@ void Abstract_Trimmer::grow(Slot &s, size_t bytes, size_t reads, bool need_seq)
 void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
 {
     ensure_device();
-    Slot &s = slots[slot];
+    Slot &s = slots[(size_t)slot];
+    sk_ctx *ctx = ctx_of(slot);
+    const int dev_slot = slot / (int)ctxs.size();
     const size_t n = reads.size();
     // Layout.  Equal-length batches (the usual case): fixed stride, uniform length -> the tiled
     // kernel with the matrix-pipe window sums.  Mixed lengths up to SK_TILE_MAX_STRIDE: the same
@@ -177,7 +205,7 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     const size_t stride = tiled ? stride8 * 8 : 0;
     const size_t bytes = tiled ? n * stride : total_len;
     const bool need_seq = trunc_n != 0;
-    grow(s, bytes, n, need_seq);
+    grow(ctx, s, bytes, n, need_seq);
 
     sk_batch b;
     memset(&b, 0, sizeof b);
@@ -216,7 +244,7 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     b.seq = need_seq ? s.seq : nullptr;
     b.n_reads = n;
     sk_params p = {qualtype, qual_threshold, length_threshold, no_fiveprime, trunc_n};
-    const int rc = sk_submit(ctx, slot, &p, &b, s.cuts);
+    const int rc = sk_submit(ctx, dev_slot, &p, &b, s.cuts);
     if (rc != SK_OK) {
         fprintf(stderr, "****Error: device scan could not be started (%d): %s\n\n", rc, sk_last_error(ctx));
         exit(EXIT_FAILURE);
@@ -227,7 +255,8 @@ const cutsites *Abstract_Trimmer::wait_scan(int slot, const std::vector<FQEntry>
 {
     static_assert(sizeof(cutsites) == sizeof(sk_cut), "cutsites must match the C ABI's sk_cut");
     sk_err e;
-    const int rc = sk_wait(ctx, slot, &e);
+    sk_ctx *ctx = ctx_of(slot);
+    const int rc = sk_wait(ctx, slot / (int)ctxs.size(), &e);
     if (rc == SK_ERANGE) {
         // reference src/trim.cpp:130-136
         const FQEntry &r = reads[e.read];
@@ -245,7 +274,7 @@ const cutsites *Abstract_Trimmer::wait_scan(int slot, const std::vector<FQEntry>
         fprintf(stderr, "****Error: device scan failed (%d): %s\n\n", rc, sk_last_error(ctx));
         exit(EXIT_FAILURE);
     }
-    return reinterpret_cast<const cutsites *>(slots[slot].cuts);
+    return reinterpret_cast<const cutsites *>(slots[(size_t)slot].cuts);
 }
 
 std::thread Abstract_Trimmer::prefetch_batches(GZReader *reader, Channel<Batch *> &out)

@@ -126,7 +126,11 @@ protected:
     Abstract_Trimmer();
 
     // ---- the scan of one batch of reads on the device (what processing_thread did on CPU threads)
+    // Two staging slots per GPU.  SICKLE_DEVICES=0,1,... spreads the batches over several GPUs
+    // (batch i goes to slot i mod n_slots(), i.e. to GPU i mod G): reads are independent, nothing
+    // is exchanged between devices and the writer keeps batch order, so the output does not change.
     static const int kSlots = 2;
+    int n_slots() const { return kSlots * (int)device_ids.size(); }
     // Creates the device session on a helper thread (HIP start-up takes ~0.2 s, which the first
     // batch's file reads hide); the first submit_scan waits for it and exits with the message
     // below if there is no usable gfx950 device.  Always returns 0.
@@ -183,12 +187,14 @@ private:
         sk_cut *cuts = nullptr;
         size_t cap_reads = 0;
     };
-    sk_ctx *ctx = nullptr;
+    std::vector<int> device_ids; // set by open_device() before it returns
+    std::vector<sk_ctx *> ctxs;  // one per entry of device_ids, created by the opener thread
+    bool devices_ok = false;
     std::thread device_opener;
-    int device_rc = 0;
     void ensure_device();
-    Slot slots[kSlots];
-    void grow(Slot &s, size_t bytes, size_t reads, bool need_seq);
+    std::vector<Slot> slots;     // n_slots(): slot s belongs to ctxs[s % G]
+    sk_ctx *ctx_of(int slot) { return ctxs[(size_t)slot % ctxs.size()]; }
+    void grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq);
 };
 
 #include "WorkerPool.h"

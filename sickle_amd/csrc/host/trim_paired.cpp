@@ -443,9 +443,10 @@ int Trim_Paired::trim_main()
         }
     });
 
-    Work *inflight[kSlots] = {nullptr, nullptr};
+    const int nslots = n_slots();
+    std::vector<Work *> inflight((size_t)nslots, nullptr);
     auto finish = [&](int slot) {
-        Work *w = inflight[slot];
+        Work *w = inflight[(size_t)slot];
         if (!w) return;
         const cutsites *cs;
         {
@@ -453,23 +454,23 @@ int Trim_Paired::trim_main()
             cs = wait_scan(slot, w->reads);
         }
         w->cuts.assign(cs, cs + w->reads.size());
-        inflight[slot] = nullptr;
+        inflight[(size_t)slot] = nullptr;
         scanned.push(w);
     };
     int i = 0;
     Work *w;
     while (parsed.pop(w)) {
-        const int slot = i % kSlots;
+        const int slot = i % nslots;
         finish(slot);
         {
             StageClock::Scope pk(clk_pack);
             submit_scan(slot, w->reads);
         }
         StageClock::mark("batch submitted");
-        inflight[slot] = w;
+        inflight[(size_t)slot] = w;
         ++i;
     }
-    for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    for (int k = 0; k < nslots; ++k) finish((i + k) % nslots);
     require_device(); // even an empty input does not succeed without the GPU
     scanned.close();
     reader.join();

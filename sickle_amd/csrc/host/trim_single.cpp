@@ -262,25 +262,26 @@ int Trim_Single::trim_main()
         }
     });
 
-    Work *inflight[kSlots] = {nullptr, nullptr};
+    const int nslots = n_slots();
+    std::vector<Work *> inflight((size_t)nslots, nullptr);
     auto finish = [&](int slot) {
-        Work *w = inflight[slot];
+        Work *w = inflight[(size_t)slot];
         if (!w) return;
         const cutsites *cs = wait_scan(slot, w->reads);
         w->cuts.assign(cs, cs + w->reads.size());
-        inflight[slot] = nullptr;
+        inflight[(size_t)slot] = nullptr;
         scanned.push(w);
     };
     int i = 0;
     Work *w;
     while (parsed.pop(w)) {
-        const int slot = i % kSlots;
+        const int slot = i % nslots;
         finish(slot);
         submit_scan(slot, w->reads);
-        inflight[slot] = w;
+        inflight[(size_t)slot] = w;
         ++i;
     }
-    for (int k = 0; k < kSlots; ++k) finish((i + k) % kSlots);
+    for (int k = 0; k < nslots; ++k) finish((i + k) % nslots);
     require_device(); // even an empty input does not succeed without the GPU
     scanned.close();
     reader.join();

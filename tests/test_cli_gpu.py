@@ -47,3 +47,17 @@ def test_range_error_exit_on_gpu(workdir):
     pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", path, "-t", c["params"]["qualtype"], "-o", "{tmp}/bad_out.fastq", "-a", "1"])
     assert pr.returncode == 1
     assert pr.stderr.decode("latin-1") == c["stderr"]
+
+
+def test_multi_device_round_robin_same_output(workdir):
+    """SICKLE_DEVICES spreads batches over several GPUs; on this one-GPU box the list names GPU 0
+    three times, which exercises the multi-context path: output must not change."""
+    rec = cu.e2e()["runs"]["pe_fr_illumina"]
+    for o in rec["outputs"]:
+        p = os.path.join(str(workdir), o)
+        if os.path.exists(p):
+            os.remove(p)
+    pr = cu.run_cli(cu.PRODUCT_BIN, workdir, rec["argv"], env={"SICKLE_DEVICES": "0,0,0"})
+    assert pr.returncode == 0, pr.stderr
+    for o, meta in rec["outputs"].items():
+        assert cu.md5_file(os.path.join(str(workdir), o)) == meta["md5"], o
