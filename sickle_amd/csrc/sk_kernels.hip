@@ -52,13 +52,6 @@ __device__ __forceinline__ uint32_t bad_flags(uint32_t x, uint32_t min4, uint32_
     return (~lo_ok | hi_bad | x) & H4;
 }
 
-// bit 7 of each byte set iff that byte == the byte of c4 (exact for the LOWEST set flag)
-__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t c4)
-{
-    uint32_t y = x ^ c4;
-    return (y - 0x01010101u) & ~y & H4;
-}
-
 // the first n bytes of x (n <= 0: none, n >= 4: all), the others taken from `filler`
 __device__ __forceinline__ uint32_t first_bytes(uint32_t x, int n, uint32_t filler)
 {
@@ -534,16 +527,39 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
             wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
             const uint32_t *srow = reinterpret_cast<const uint32_t *>(buf1 + (size_t)lane * stride);
-            int ni = INF, Ni = INF;
-            for (int k = 0; 4 * k < Lmax; ++k) {
-                const uint32_t x = srow[k];
-                const uint32_t fn = keep_first(eq_flags(x, splat('n')), L - 4 * k);
-                const uint32_t fN = keep_first(eq_flags(x, splat('N')), L - 4 * k);
-                if (fn && ni == INF) ni = 4 * k + (__builtin_ctz(fn) >> 3);
-                if (fN && Ni == INF) Ni = 4 * k + (__builtin_ctz(fN) >> 3);
+            // 'n' (0x6e) and 'N' (0x4e) differ in bit 5 only: one zero-byte test on (c | 0x20) ^ 'n'
+            // flags both, bit 5 of the original byte tells them apart.  nlo = bit index of the first
+            // lowercase n (NONE if none), anyN = whether an uppercase N occurs at all.
+            uint32_t nlo = NONE, anyN = 0;
+            auto n_step = [&](uint32_t x, uint32_t rel) {
+                const uint32_t y = (x | 0x20202020u) ^ 0x6e6e6e6eu;
+                // exact zero-byte flags (the shorter (y-0x01..)&~y form also flags a 0x01 byte above
+                // a zero byte, i.e. an 'o' right after an 'N')
+                const uint32_t either = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & H4;
+                const uint32_t lower = either & (x << 2);            // bit 5 of the byte moved onto its flag
+                nlo = min(nlo, __builtin_elementwise_add_sat(ffbl_or_none(lower), rel));
+                anyN |= either ^ lower;
+            };
+            {
+                int k = 0;
+                if (UNIFORM) {
+                    const int full = Lmax >> 2;
+                    const uint64_t *srow64 = reinterpret_cast<const uint64_t *>(srow);
+                    for (; k + 8 <= full; k += 8) {
+                        uint64_t x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) x[u] = srow64[(k >> 1) + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            n_step((uint32_t)x[u], 32u * (uint32_t)(k + 2 * u));
+                            n_step((uint32_t)(x[u] >> 32), 32u * (uint32_t)(k + 2 * u + 1));
+                        }
+                    }
+                }
+                for (; 4 * k < Lmax; ++k) n_step(first_bytes(srow[k], L - 4 * k, 0u), 32u * (uint32_t)k);
             }
-            if (ni != INF) three = ni - 1;
-            else if (Ni != INF) three = -2;
+            if (nlo != NONE) three = (int)(nlo >> 3) - 1;
+            else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane); // S(t+1)
         } else if (NBUF == 1 && ABLATE != 2) {

@@ -227,3 +227,27 @@ def test_async_slots_overlap(sk_ctx):
     for qs, out in batches:
         want, _ = ob.oracle_trim_batch(po, qs, stride=152, read_len=150, n_reads=40_000, threads=4)
         assert (out == want).all()
+
+
+def test_trunc_n_adversarial_sequences(sk_ctx):
+    """Sequence bytes chosen to break byte-parallel n/N searches: o/O and m/M next to n/N, n and N in
+    every order and alignment, bytes >= 0x80."""
+    rng = np.random.default_rng(5)
+    n, L = 20_000, 150
+    _, qual = synth.make_reads(8, n, L, "sanger")
+    alphabet = np.frombuffer(b"ACGTACGTACGTNnoOmMpP\x6f\xee\xce", dtype=np.uint8)
+    seq = alphabet[rng.integers(0, len(alphabet), size=(n, L))]
+    seq[rng.random((n, L)) < 0.93] = ord("A")
+    for trial, (stride, lens) in enumerate(((152, None), (160, rng.integers(1, 151, size=n).astype(np.uint32)))):
+        qs, ss = synth.pack_fixed(qual, stride), synth.pack_fixed(seq, stride)
+        p, po = both_params("sanger", 20, 20, 0, 1)
+        kw = dict(stride=stride, n_reads=n)
+        if lens is None:
+            kw["read_len"] = L
+        else:
+            kw["lengths"] = lens
+        want, err = ob.oracle_trim_batch(po, qs, ss, threads=4, **kw)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qs, ss, **kw)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (trial, bad[:5], got[bad[:5]], want[bad[:5]], bytes(seq[bad[0]]))
