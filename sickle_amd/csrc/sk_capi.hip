@@ -118,6 +118,8 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->lthr = p->length_threshold;
     a->no5 = p->no_fiveprime ? 1 : 0;
     a->truncn = p->trunc_n ? 1 : 0;
+    static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
+    a->tile_order = order;
     return SK_OK;
 }
 

@@ -28,6 +28,7 @@ struct sk_scan_args {
     int32_t lthr;      // length_threshold
     int32_t no5;       // -x
     int32_t truncn;    // -n
+    int32_t tile_order; // diagnostic (SK_TILE_ORDER): 0 = tile t on workgroup t mod G, 1 = contiguous tile ranges per XCD
 };
 
 extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,

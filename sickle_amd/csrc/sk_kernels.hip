@@ -230,8 +230,14 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     uint8_t *buf1 = LDS_BUFS > 1 ? buf0 + buf_bytes : buf0;
 
     const uint64_t n_tiles = (a.n_reads + 63) >> 6;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+    uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
     const uint64_t wave_count = (uint64_t)gridDim.x * waves_per_block;
+    if (a.tile_order == 1 && (wave_count & 7) == 0) {
+        // workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD group a
+        // contiguous run of wave slots, so that it streams a contiguous eighth of every stripe
+        const uint64_t per = wave_count >> 3;
+        wave_global = (wave_global & 7) * per + (wave_global >> 3);
+    }
 
     const uint32_t min4 = splat((uint32_t)a.qmin), max4 = splat((uint32_t)a.qmax);
     const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));

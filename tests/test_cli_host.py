@@ -185,3 +185,33 @@ def test_gzip_output_roundtrip(hostcheck, workdir):
     assert cu.run_cli(hostcheck, workdir, ["se", "-f", src, "-t", "illumina", "-o", out, "-g", "-a", "1"]).returncode == 0
     assert cu.run_cli(hostcheck, workdir, ["se", "-f", src, "-t", "illumina", "-o", plain, "-a", "1"]).returncode == 0
     assert gzip.open(out, "rb").read() == open(plain, "rb").read()
+
+
+def test_empty_and_truncated_inputs(hostcheck, workdir):
+    """An empty file, a file that is all one partial record, and a file whose last record is cut
+    short: the reference returns no batch / drops the tail (src/GZReader.cpp:29-41,104-129)."""
+    d = str(workdir)
+    rec = b"@r%d\nACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIII\n"
+    cases = {
+        "empty.fastq": (b"", 0),
+        "partial_only.fastq": (b"@r1\nACGT\n+\n", 0),
+        "cut_tail.fastq": (b"".join(rec % i for i in range(40)) + b"@r40\nACGTACGTAC\n", 40),
+    }
+    for name, (data, kept) in cases.items():
+        path = os.path.join(d, name)
+        open(path, "wb").write(data)
+        out = os.path.join(d, name + ".out")
+        pr = cu.run_cli(hostcheck, workdir, ["se", "-f", path, "-t", "sanger", "-o", out, "-a", "1"])
+        assert pr.returncode == 0, (name, pr.stderr)
+        assert ("FastQ records kept: %d\n" % kept).encode() in pr.stdout, (name, pr.stdout)
+        got = parse_fastq(open(out, "rb").read())
+        assert len(got) == kept
+    if ob.have_ref():  # the same three files through the reference's working driver (self-paired pe)
+        for name, (data, kept) in cases.items():
+            path = os.path.join(d, name)
+            copy = os.path.join(d, "copy_" + name)
+            open(copy, "wb").write(data)
+            pr = subprocess.run([ob.REF_BIN, "pe", "-f", path, "-r", copy, "-t", "sanger", "-o", path + ".r1", "-p",
+                                 path + ".r2", "-s", path + ".rs", "-a", "1"], capture_output=True, timeout=60)
+            assert pr.returncode == 0
+            assert open(path + ".r1", "rb").read() == open(os.path.join(d, name + ".out"), "rb").read(), name

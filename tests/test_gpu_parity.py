@@ -251,3 +251,38 @@ def test_trunc_n_adversarial_sequences(sk_ctx):
         got = sk_ctx.trim_batch(p, qs, ss, **kw)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert bad.size == 0, (trial, bad[:5], got[bad[:5]], want[bad[:5]], bytes(seq[bad[0]]))
+
+
+def test_long_reads_and_tile_boundary(sk_ctx):
+    """Lengths around the tiled kernel's limit (stride 504 / 512) and long reads (up to 30 kb)
+    through the general kernel, all against the oracle."""
+    rng = np.random.default_rng(21)
+    lens = np.array([329, 339, 340, 341, 400, 496, 503, 504, 505, 511, 512, 513, 1000, 4097, 30_000] * 8, dtype=np.uint32)
+    rng.shuffle(lens)
+    n = len(lens)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    tot = int(offs[-1])
+    qual = np.clip(rng.normal(60, 9, tot).astype(int), 33, 74).astype(np.uint8)
+    # long stretches of low quality so that 3' cuts land deep inside long reads
+    for i in range(n):
+        a, b = int(offs[i]), int(offs[i + 1])
+        cut = a + int(rng.integers(0, b - a))
+        qual[cut:b] = np.clip(rng.normal(40, 6, b - cut).astype(int), 33, 74)
+    seq = rng.choice(np.frombuffer(b"ACGT" * 200 + b"Nn", dtype=np.uint8), size=tot)
+    for q, l, x, tn in ((20, 20, 0, 0), (25, 100, 1, 1), (18, 0, 0, 1)):
+        p, po = both_params("sanger", q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=4)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offs)
+        assert (got == want).all(), (q, l, x, tn, np.nonzero((got != want).any(axis=1))[0][:5])
+    # uniform batches right at the tiled limit: 504 (tiled, stride 504) and 505 (general kernel)
+    for L in (339, 340, 504, 505):
+        m = 1000
+        _, qm = synth.make_reads(L, m, L, "sanger")
+        stride = L if L == 505 else ((L + 7) // 8 | 1) * 8
+        qs = synth.pack_fixed(qm, stride)
+        p, po = both_params("sanger", 20, 20, 0, 0)
+        want, _ = ob.oracle_trim_batch(po, qs, stride=stride, read_len=L, n_reads=m)
+        got = sk_ctx.trim_batch(p, qs, stride=stride, read_len=L, n_reads=m)
+        assert (got == want).all(), L

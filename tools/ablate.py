@@ -10,7 +10,7 @@ import bench
 class Args(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("stride", C.c_uint32), ("read_len", C.c_uint32), ("qmin", C.c_int32),
                 ("qmax", C.c_int32), ("craw", C.c_int32), ("cthr", C.c_int32), ("cthr_raw", C.c_int32),
-                ("lthr", C.c_int32), ("no5", C.c_int32), ("truncn", C.c_int32)]
+                ("lthr", C.c_int32), ("no5", C.c_int32), ("truncn", C.c_int32), ("tile_order", C.c_int32)]
 
 lib = C.CDLL(os.environ.get("SK_LIB", os.path.join(ROOT, "sickle_amd", "libsickle_amd.so")))
 lib.sk_launch_tile_ablate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 q = bench.synth_quals_device(torch, n, 150, 152, 1234, dev)
 out = torch.empty((n, 2), dtype=torch.int32, device=dev)
 err = torch.full((1,), -1, dtype=torch.int64, device=dev)
-a = Args(n, 152, 150, 33, 126, 53, 53, 53, 20, 0, 0)
+a = Args(n, 152, 150, 33, 126, 53, 53, 53, 20, 0, 0, int(os.environ.get('SK_TILE_ORDER', '0')))
 s = torch.cuda.Stream(dev)
 torch.cuda.synchronize()
 NAMES = {0: "2buf mfma full", 1: "2buf dma-only", 2: "2buf mfma scan-only", 10: "2buf valu full", 12: "2buf valu scan-only",
