@@ -106,6 +106,9 @@ __device__ __forceinline__ void report_error(unsigned long long *errword, uint64
 // cache policy of the tile DMA (the aux operand of global_load_lds): 0 = default, 2 = nt.
 // Every tile byte is read exactly once, so nt: measured -9 % on the DMA-only floor and -8 % on the
 // whole kernel against the default policy (interleaved A/B on one device, tools/ablate.py).
+#ifndef SK_TAIL_PRIO
+#define SK_TAIL_PRIO 0
+#endif
 #ifndef SK_DMA_AUX
 #define SK_DMA_AUX 2
 #endif
@@ -495,6 +498,11 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         // the dwords k..k+trips-1.  Addresses do not depend on the data, so the reads pipeline;
         // a hit is tracked as the bit index of its flag (8*pos + 7), NONE until found.
         int five = 0, three = L;
+#if SK_TAIL_PRIO
+        // the tail of a tile (hit searches, then the refill DMA) runs at raised priority: the sooner
+        // a wave gets its buffer back in flight, the fuller the DMA queue of the CU stays
+        __builtin_amdgcn_s_setprio(SK_TAIL_PRIO);
+#endif
         {
             const int k5 = i0 >> 2, k3 = i1 >> 2;
             const int trips = (wmax + 3) / 4 + 1;
@@ -574,6 +582,9 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
         }
+#if SK_TAIL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
         // ---- trim.cpp:103-108
         if (!scanned || !found5 || (three - five < a.lthr)) {
