@@ -286,3 +286,32 @@ def test_long_reads_and_tile_boundary(sk_ctx):
         want, _ = ob.oracle_trim_batch(po, qs, stride=stride, read_len=L, n_reads=m)
         got = sk_ctx.trim_batch(p, qs, stride=stride, read_len=L, n_reads=m)
         assert (got == want).all(), L
+
+
+def test_uniform_length_sweep(sk_ctx):
+    """Every uniform read length 1..345 (the matrix path covers w <= 33, i.e. L <= 339; beyond it
+    the vector path), at the stride the host packer would pick, three encodings, with and
+    without -x / -n, against the oracle."""
+    rng = np.random.default_rng(314)
+    for L in list(range(1, 346)):
+        n = 193  # three tiles + a partial one
+        qt = ("sanger", "illumina", "solexa")[L % 3]
+        lo, hi = {"sanger": (33, 74), "solexa": (59, 105), "illumina": (64, 105)}[qt]
+        mid = int(rng.integers(lo + 5, hi - 5))
+        qual = np.clip(mid + rng.integers(-14, 15, size=(n, L)), lo, hi).astype(np.uint8)
+        drop = rng.integers(0, L + 1, size=n)
+        qual[np.arange(L)[None, :] >= drop[:, None]] = lo + 1  # a 3' collapse somewhere
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))].copy()
+        seq[rng.random((n, L)) < 0.01] = ord("N")
+        seq[rng.random((n, L)) < 0.003] = ord("n")
+        stride = ((L + 7) // 8 | 1) * 8
+        qs, ss = synth.pack_fixed(qual, stride), synth.pack_fixed(seq, stride)
+        q = int(rng.integers(0, 42))
+        l = int(rng.integers(0, max(1, L)))
+        x, tn = L % 2, (L // 2) % 2
+        p, po = both_params(qt, q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qs, ss, stride=stride, read_len=L, n_reads=n)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qs, ss, stride=stride, read_len=L, n_reads=n)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (L, qt, q, l, x, tn, bad[:4], got[bad[:4]], want[bad[:4]])
