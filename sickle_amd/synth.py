@@ -83,3 +83,31 @@ def fastq_bytes_ragged(seq, qual, offsets, prefix="SYN:", start=0, suffix="", pl
         parts.append(qual[a:b].tobytes())
         parts.append(b"\n")
     return b"".join(parts)
+
+
+def fastq_bytes_fast(seq, qual, prefix="SYN:", start=0, suffix="", plus="+"):
+    """Same bytes as fastq_bytes() for fixed-length matrices, built as one (n, record) byte matrix."""
+    n, length = seq.shape
+    head = ("@" + prefix).encode()
+    tail = suffix.encode() + b"\n"
+    mid = b"\n" + plus.encode() + b"\n"
+    width = len(head) + 9 + len(tail) + length + len(mid) + length + 1
+    rec = np.empty((n, width), dtype=np.uint8)
+    c = 0
+    rec[:, c:c + len(head)] = np.frombuffer(head, dtype=np.uint8)
+    c += len(head)
+    ids = np.arange(start, start + n, dtype=np.int64)
+    for d in range(9):
+        rec[:, c + 8 - d] = (ids % 10 + 48).astype(np.uint8)
+        ids //= 10
+    c += 9
+    rec[:, c:c + len(tail)] = np.frombuffer(tail, dtype=np.uint8)
+    c += len(tail)
+    rec[:, c:c + length] = seq
+    c += length
+    rec[:, c:c + len(mid)] = np.frombuffer(mid, dtype=np.uint8)
+    c += len(mid)
+    rec[:, c:c + length] = qual
+    c += length
+    rec[:, c] = 10
+    return rec.tobytes()

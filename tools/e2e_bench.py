@@ -11,6 +11,8 @@ import sys
 import tempfile
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sickle_amd import synth  # noqa: E402
@@ -28,14 +30,19 @@ def md5(path):
 
 
 def write_pair(d, n, chunk=250_000):
+    """Two FASTQ files of n reads each.  The read content cycles through one seeded block of
+    `chunk` reads per file (rotated per block), the headers count up: cheap to generate at tens
+    of millions of reads, and still a different byte stream in every block."""
     p1, p2 = os.path.join(d, "R1.fastq"), os.path.join(d, "R2.fastq")
+    s1, q1 = synth.make_reads(1000, chunk, 150, "sanger")
+    s2, q2 = synth.make_reads(5000, chunk, 150, "sanger")
     with open(p1, "wb") as f1, open(p2, "wb") as f2:
-        for a in range(0, n, chunk):
+        for k, a in enumerate(range(0, n, chunk)):
             m = min(chunk, n - a)
-            s1, q1 = synth.make_reads(1000 + a, m, 150, "sanger")
-            s2, q2 = synth.make_reads(5000 + a, m, 150, "sanger")
-            f1.write(synth.fastq_bytes(s1, q1, start=a, suffix="/1"))
-            f2.write(synth.fastq_bytes(s2, q2, start=a, suffix="/2"))
+            r = (k * 7919) % chunk
+            idx = (np.arange(m) + r) % chunk
+            f1.write(synth.fastq_bytes_fast(s1[idx], q1[idx], start=a, suffix="/1"))
+            f2.write(synth.fastq_bytes_fast(s2[idx], q2[idx], start=a, suffix="/2"))
     return p1, p2
 
 
