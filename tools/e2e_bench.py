@@ -71,6 +71,17 @@ def main():
             res["ref_a1_s"] = t_ref1
             res["ref_a1_reads_per_s"] = 2 * n / t_ref1
             res["identical_to_ref_a1"] = m_ref1 == m_new
+            if m_ref1 != m_new:
+                # the reference's per-batch output threads race each other for the file
+                # (src/trim_paired.cpp:445-458), so on many-batch inputs its batch ORDER can differ
+                # from run to run: compare the records themselves, order-independently
+                fp = os.path.join(ROOT, "tools", "probes", "fq_fingerprint.bin")
+                same = []
+                for k in ("o1", "o2", "os"):
+                    a = subprocess.run([fp, os.path.join(d, "new_%s.fastq" % k)], capture_output=True).stdout
+                    b = subprocess.run([fp, os.path.join(d, "ref1_%s.fastq" % k)], capture_output=True).stdout
+                    same.append(a == b and len(a) > 0)
+                res["same_records_as_ref_a1"] = all(same)
             cores = len(os.sched_getaffinity(0))
             cores = min(cores, 16)
             t_refn, _ = run(REF, d, "refn", p1, p2, cores)
