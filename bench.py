@@ -109,8 +109,8 @@ def cpu_baseline(qual_host, n, stride, length, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--len", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -746,7 +746,7 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
 
 } // namespace
 
-extern "C" hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream)
 {
@@ -795,7 +795,7 @@ extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cu
 #undef SK_GO
 }
 
-extern "C" hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                      const sk_scan_args *a, int cu_count, hipStream_t stream)
 {
