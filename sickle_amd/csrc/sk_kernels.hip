@@ -219,7 +219,10 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                     unsigned long long *errword, sk_scan_args a)
 {
     static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
-    constexpr int LDS_BUFS = HAS_SEQ ? 2 : NBUF;
+    // -n: NBUF == 2 keeps the quality and the sequence tile in two buffers (8 waves per CU);
+    // NBUF == 1 runs both through ONE buffer, one after the other (16 waves per CU)
+    constexpr int LDS_BUFS = NBUF;
+    constexpr bool SEQ_SHARES = HAS_SEQ && NBUF == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tells the compiler this is one value per wave, so that the tile index and
@@ -293,7 +296,7 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     // prologue: Q(t) [and S(t)] in flight
     uint32_t cur_bytes = tile_bytes_of(t);
     tile_to_lds(qual + (t << 6) * stride, buf0, cur_bytes, lane);
-    if (HAS_SEQ) tile_to_lds(seq + (t << 6) * stride, buf1, cur_bytes, lane);
+    if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + (t << 6) * stride, buf1, cur_bytes, lane);
     int len_next = 0;
     if (!UNIFORM) {
         const uint64_t r = (t << 6) + lane;
@@ -320,7 +323,10 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             }
         }
 
-        if (HAS_SEQ) {
+        if (SEQ_SHARES) {
+            tile = buf0;
+            wait_vmcnt(0); // Q(t)
+        } else if (HAS_SEQ) {
             tile = buf0;
             // outstanding, oldest first: Q(t), S(t) [, store(t-1) before them]
             wait_vmcnt(tile_pieces(cur_bytes));
@@ -536,11 +542,17 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 
         // ---- the N rule: trim.cpp:86-98 (lowercase n: cut before it; only uppercase N: cut = -2)
         if (HAS_SEQ) {
-            // buf0 is free now: start Q(t+1), then retire S(t)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
-            wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
-            const uint32_t *srow = reinterpret_cast<const uint32_t *>(buf1 + (size_t)lane * stride);
+            if (SEQ_SHARES) {
+                // the quality scan is over: the same buffer now takes the sequence tile of these reads
+                tile_to_lds(seq + r0 * stride, buf0, cur_bytes, lane);
+                wait_vmcnt(0);
+            } else {
+                // buf0 is free now: start Q(t+1), then retire S(t)
+                if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+                wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
+            }
+            const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)lane * stride);
             // 'n' (0x6e) and 'N' (0x4e) differ in bit 5 only: one zero-byte test on (c | 0x20) ^ 'n'
             // flags both, bit 5 of the original byte tells them apart.  nlo = bit index of the first
             // lowercase n (NONE if none), anyN = whether an uppercase N occurs at all.
@@ -575,7 +587,10 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             if (nlo != NONE) three = (int)(nlo >> 3) - 1;
             else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane); // S(t+1)
+            if (more) {
+                if (SEQ_SHARES) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane); // Q(t+1)
+                else tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane);             // S(t+1)
+            }
         } else if (NBUF == 1 && ABLATE != 2) {
             // single buffer: every LDS read of this tile is done, refill it now -- the cut store
             // below and the other waves of the CU cover the DMA latency
@@ -757,6 +772,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
     const bool mfma = uniform && wu <= 33 && a->read_len > 0;
     const int nbuf = tile_nbuf_default();
 #define SK_GO(KERN, BUFS) launch_tile_kernel(KERN, BUFS, qual, seq, lengths, out, errword, a, cu_count, 0, stream)
+    if (has_seq && nbuf == 1) {
+        if (mfma) return SK_GO((sk_scan_tile_kernel<true, true, true, 1>), 1);
+        if (uniform) return SK_GO((sk_scan_tile_kernel<true, true, false, 1>), 1);
+        return SK_GO((sk_scan_tile_kernel<false, true, false, 1>), 1);
+    }
     if (has_seq) {
         if (mfma) return SK_GO((sk_scan_tile_kernel<true, true, true, 2>), 2);
         if (uniform) return SK_GO((sk_scan_tile_kernel<true, true, false, 2>), 2);
