@@ -54,6 +54,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SickleError("%s is missing: build it with `make -C sickle_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # torch (when installed) bundles its own copy of the HIP runtime, and a process can only
+        # initialise one: whichever copy is loaded first wins and the other then sees no device.
+        # Load torch's first, so that a later `import torch` in the same process (bench.py, the
+        # tests) still works; libsickle_amd.so binds to the copy that is already there.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sk_quality_constants.restype = C.POINTER(C.c_int32)
         L.sk_quality_constants.argtypes = [C.c_int32]
