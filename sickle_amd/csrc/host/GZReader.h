@@ -99,7 +99,9 @@ private:
     void index_more();  // find the newlines of the bytes not yet indexed
 
     gzFile file = nullptr; // gzip input
-    int fd = -1;           // plain input: read(2), no zlib copy
+    int fd = -1;           // plain input: read(2) / parallel pread(2), no zlib copy
+    bool regular = false;  // a regular file of known size: blocks are pread in parallel slices
+    uint64_t file_size = 0, file_pos = 0;
     bool eof = false;      // gzgets would have returned NULL: no further batch
     bool in_eof = false;   // the underlying stream is exhausted
     int batch_len;

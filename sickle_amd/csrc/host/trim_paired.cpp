@@ -244,7 +244,7 @@ void Trim_Paired::close_streams()
 // Pair classification and the three output streams of one ingest batch: reference
 // src/trim_paired.cpp:515-624.  Pair k of the batch sits in queue k mod T and the queues are
 // written one after the other (:388-403, :530-533), so -a T > 1 gives queue-major file order.
-void Trim_Paired::output_paired(Work &w)
+Trim_Paired::Assembled *Trim_Paired::output_paired(Work &w)
 {
     const size_t pairs = w.reads.size() / 2;
     const size_t T = (size_t)threads;
@@ -315,19 +315,32 @@ void Trim_Paired::output_paired(Work &w)
     // so the summary's "Total input FastQ records" is the size of the last batch written.
     total = b_kept_p + b_kept_s1 + b_kept_s2 + b_discard_p + b_discard_s1 + b_discard_s2;
 
-    // the output files are independent: write them side by side
-    std::thread t2, t3;
-    if (!inter)
-        t2 = std::thread([&] { for (const Part &o : part_out) outfile2.write(o.fq2); });
-    if (sfn)
-        t3 = std::thread([&] { for (const Part &o : part_out) outfile_single.write(o.singles); });
-    OutFile &first = inter ? outfile_interleaved : outfile;
-    for (const Part &o : part_out) first.write(o.fq1);
-    if (t2.joinable()) t2.join();
-    if (t3.joinable()) t3.join();
+    Assembled *a = new Assembled();
+    for (Part &o : part_out) {
+        a->fq1.push_back(std::move(o.fq1));
+        a->fq2.push_back(std::move(o.fq2));
+        a->singles.push_back(std::move(o.singles));
+    }
     delete w.batch;
     delete w.batch2;
     w.batch = w.batch2 = nullptr;
+    return a;
+}
+
+void Trim_Paired::write_assembled(Assembled *a)
+{
+    // the output files are independent: write them side by side
+    const bool inter = input_inter != nullptr;
+    std::thread t2, t3;
+    if (!inter)
+        t2 = std::thread([&] { for (const std::string &t : a->fq2) outfile2.write(t); });
+    if (sfn)
+        t3 = std::thread([&] { for (const std::string &t : a->singles) outfile_single.write(t); });
+    OutFile &first = inter ? outfile_interleaved : outfile;
+    for (const std::string &t : a->fq1) first.write(t);
+    if (t2.joinable()) t2.join();
+    if (t3.joinable()) t3.join();
+    delete a;
 }
 
 int Trim_Paired::trim_main()
@@ -433,12 +446,25 @@ int Trim_Paired::trim_main()
         if (!input_inter)
             while (raw2.pop(rest)) delete rest;
     });
+    // assembly of batch i+1 overlaps the file writes of batch i
+    Channel<Assembled *> assembled(1);
+    StageClock clk_write;
     std::thread writer([&] {
         Work *w;
         while (scanned.pop(w)) {
             StageClock::Scope o(clk_out);
-            output_paired(*w);
+            Assembled *a = output_paired(*w);
             delete w;
+            o.stop();
+            assembled.push(a);
+        }
+        assembled.close();
+    });
+    std::thread flusher([&] {
+        Assembled *a;
+        while (assembled.pop(a)) {
+            StageClock::Scope o(clk_write);
+            write_assembled(a);
             StageClock::mark("batch written");
         }
     });
@@ -477,8 +503,9 @@ int Trim_Paired::trim_main()
     fetch1.join();
     if (fetch2.joinable()) fetch2.join();
     writer.join();
+    flusher.join();
     StageClock::report({{"read+index", &clk_read}, {"frame", &clk_frame}, {"pack+submit", &clk_pack},
-                        {"device wait", &clk_wait}, {"classify+write", &clk_out}});
+                        {"device wait", &clk_wait}, {"classify+assemble", &clk_out}, {"write", &clk_write}});
 
     if (!quiet) { // reference src/trim_paired.cpp:464-476
         if (infn && infn2) fprintf(stdout, "\nPE forward file: %s\nPE reverse file: %s\n", infn, infn2);

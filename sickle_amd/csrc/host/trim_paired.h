@@ -21,7 +21,13 @@ protected:
     };
     int init_streams();
     void close_streams();
-    void output_paired(Work &w);
+    // the text of one batch for the three outputs, in pieces (one per host thread), in order
+    struct Assembled {
+        std::vector<std::string> fq1, fq2, singles;
+    };
+    // classifies the pairs of a batch and builds their output text; updates the counters
+    Assembled *output_paired(Work &w);
+    void write_assembled(Assembled *a); // the three files side by side; deletes a
 
     GZReader *input2;
     GZReader *input_inter;

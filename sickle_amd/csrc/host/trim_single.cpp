@@ -170,7 +170,7 @@ void Trim_Single::close_streams()
 // One ingest batch -> output text.  The reference deals read k of a batch into queue (k+1) mod T
 // and writes the queues one after the other (src/trim_single.cpp:263-298, :382-405), so with
 // -a T > 1 the records of a batch come out queue-major.  Reproduced, since it is the file order.
-void Trim_Single::output_single(Work &w)
+std::vector<std::string> *Trim_Single::output_single(Work &w)
 {
     const size_t n = w.reads.size();
     const size_t T = (size_t)threads;
@@ -218,11 +218,11 @@ void Trim_Single::output_single(Work &w)
     for (size_t part = 0; part < parts; ++part) {
         kept += part_kept[part];
         discard += part_discard[part];
-        outfile.write(text[part]);
     }
     total = kept + discard;
     delete w.batch;
     w.batch = nullptr;
+    return new std::vector<std::string>(std::move(text));
 }
 
 int Trim_Single::trim_main()
@@ -254,11 +254,21 @@ int Trim_Single::trim_main()
         }
         parsed.close();
     });
+    // assembly of batch i+1 overlaps the file write of batch i
+    Channel<std::vector<std::string> *> assembled(1);
     std::thread writer([&] {
         Work *w;
         while (scanned.pop(w)) {
-            output_single(*w);
+            assembled.push(output_single(*w));
             delete w;
+        }
+        assembled.close();
+    });
+    std::thread flusher([&] {
+        std::vector<std::string> *text;
+        while (assembled.pop(text)) {
+            for (const std::string &t : *text) outfile.write(t);
+            delete text;
         }
     });
 
@@ -287,6 +297,7 @@ int Trim_Single::trim_main()
     reader.join();
     fetcher.join();
     writer.join();
+    flusher.join();
 
     if (!quiet)
         fprintf(stdout, "\nSE input file: %s\n\nTotal FastQ records: %d\nFastQ records kept: %d\nFastQ records discarded: %d\n\n",

@@ -21,7 +21,8 @@ private:
         std::vector<FQEntry> reads;
         std::vector<cutsites> cuts;
     };
-    void output_single(Work &w);
+    // builds the output text of one batch, in pieces, in file order; updates the counters
+    std::vector<std::string> *output_single(Work &w);
     OutFile outfile;
 };
 
