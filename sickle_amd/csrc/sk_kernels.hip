@@ -14,18 +14,23 @@
 // 3' break fired, the whole read otherwise, nothing if L < length_threshold.
 //
 // Two kernels:
-//   sk_scan_tile_kernel   fixed-stride batches.  One LANE per read, one wavefront per
-//                         64-read tile.  The tile (64*stride contiguous bytes) goes HBM ->
-//                         LDS with global_load_lds_dwordx4 (fully coalesced, no VGPR round
-//                         trip); each lane then walks its own row in LDS 4 windows per
-//                         dword with byte-parallel arithmetic: signed byte differences
-//                         lead-trail, v_dot4c to advance the running sum, v_alignbit to
-//                         shift the sign bit of (S_i - T) into a 32-window mask.
+//   sk_scan_tile_kernel   fixed-stride batches.  One LANE per read, one wavefront per 64-read
+//                         tile, 16 single-wave workgroups per CU.  The tile (64*stride contiguous
+//                         bytes) goes HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, nt policy:
+//                         coalesced, no VGPR round trip).  Uniform-length batches take their window
+//                         sums from the integer matrix pipe (band(w) x Q as two
+//                         v_mfma_i32_32x32x32_i8 per 32 windows x 32 reads, the B operand read
+//                         straight out of the LDS rows) and spend one v_alignbit per window on the
+//                         vector ALU to collect the signs of S_i - T; mixed-length batches walk
+//                         their rows 4 windows per dword with byte-parallel arithmetic
+//                         (v_alignbyte, signed byte differences, v_dot4_i32_i8, v_alignbit).
+//                         Range check: two v_sad_u8 per dword.
 //   sk_scan_wave_kernel   any layout (ragged offsets, odd strides, long reads).  One
 //                         WAVEFRONT per read; each lane owns a contiguous run of windows,
 //                         seeds its window sum directly and rolls it in a register; the
 //                         per-lane first-hits are combined with wave min-reductions.
-// No MFMA: this is byte streaming, HBM-bound (algorithmic bytes: L + 8 per read, 2L + 8 with -n).
+// HBM-bound byte streaming (algorithmic bytes: L + 8 per read, 2L + 8 with -n); the MFMAs are a
+// way to take instructions off the vector ALU, not the bound.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
