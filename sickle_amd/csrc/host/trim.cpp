@@ -2,7 +2,9 @@
 
 #include "WorkerPool.h"
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -33,16 +35,41 @@ bool OutFile::open(const char *path, bool gzip)
         if (gz) gzbuffer(gz, 1u << 20);
         return gz != nullptr;
     }
-    fp = fopen(path, "w");
-    if (fp) setvbuf(fp, nullptr, _IOFBF, 4u << 20);
-    return fp != nullptr;
+    fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    pos = 0;
+    struct stat st;
+    seekable = fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    return fd >= 0;
+}
+
+static void write_all(int fd, const char *p, size_t n)
+{
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w <= 0) return;
+        p += w;
+        n -= (size_t)w;
+    }
+}
+
+static void pwrite_all(int fd, const char *p, size_t n, uint64_t at)
+{
+    while (n) {
+        const ssize_t w = pwrite(fd, p, n, (off_t)at);
+        if (w <= 0) return; // like the reference's ofstream: write errors are not reported
+        p += w;
+        n -= (size_t)w;
+        at += (uint64_t)w;
+    }
 }
 
 void OutFile::write(const std::string &data)
 {
     if (data.empty()) return;
-    if (fp) {
-        fwrite(data.data(), 1, data.size(), fp);
+    if (fd >= 0) {
+        if (seekable) pwrite_all(fd, data.data(), data.size(), pos);
+        else write_all(fd, data.data(), data.size());
+        pos += data.size();
     } else if (gz) {
         // The reference hands the text to gzprintf as the FORMAT string (src/trim_single.cpp:418),
         // which mangles any '%' (= Sanger Q4).  This writes the bytes themselves.
@@ -55,11 +82,25 @@ void OutFile::write(const std::string &data)
     }
 }
 
+void OutFile::write_parts(const std::vector<std::string> &parts)
+{
+    if (fd < 0 || !seekable) {
+        for (const std::string &p : parts) write(p);
+        return;
+    }
+    std::vector<uint64_t> at(parts.size() + 1, pos);
+    for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].size();
+    WorkerPool::instance().parallel_for(parts.size(), parts.size(), [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; ++i) pwrite_all(fd, parts[i].data(), parts[i].size(), at[i]);
+    });
+    pos = at[parts.size()];
+}
+
 void OutFile::close()
 {
-    if (fp) fclose(fp);
+    if (fd >= 0) ::close(fd);
     if (gz) gzclose(gz);
-    fp = nullptr;
+    fd = -1;
     gz = nullptr;
 }
 

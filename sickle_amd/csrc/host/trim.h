@@ -32,11 +32,16 @@ class OutFile {
 public:
     bool open(const char *path, bool gzip);
     void write(const std::string &data);
+    // the pieces of one batch, in order: plain files take them as concurrent pwrite(2) slices
+    // (a single write stream is a page-cache memcpy on one core), gzip files one after the other
+    void write_parts(const std::vector<std::string> &parts);
     void close();
-    bool is_open() const { return fp || gz; }
+    bool is_open() const { return fd >= 0 || gz; }
 
 private:
-    FILE *fp = nullptr;
+    int fd = -1;
+    bool seekable = false; // a regular file: positional writes; pipes and devices get plain write(2)
+    uint64_t pos = 0;
     gzFile gz = nullptr;
 };
 

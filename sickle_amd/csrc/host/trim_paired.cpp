@@ -333,11 +333,11 @@ void Trim_Paired::write_assembled(Assembled *a)
     const bool inter = input_inter != nullptr;
     std::thread t2, t3;
     if (!inter)
-        t2 = std::thread([&] { for (const std::string &t : a->fq2) outfile2.write(t); });
+        t2 = std::thread([&] { outfile2.write_parts(a->fq2); });
     if (sfn)
-        t3 = std::thread([&] { for (const std::string &t : a->singles) outfile_single.write(t); });
+        t3 = std::thread([&] { outfile_single.write_parts(a->singles); });
     OutFile &first = inter ? outfile_interleaved : outfile;
-    for (const std::string &t : a->fq1) first.write(t);
+    first.write_parts(a->fq1);
     if (t2.joinable()) t2.join();
     if (t3.joinable()) t3.join();
     delete a;

@@ -267,7 +267,7 @@ int Trim_Single::trim_main()
     std::thread flusher([&] {
         std::vector<std::string> *text;
         while (assembled.pop(text)) {
-            for (const std::string &t : *text) outfile.write(t);
+            outfile.write_parts(*text);
             delete text;
         }
     });

@@ -215,3 +215,14 @@ def test_empty_and_truncated_inputs(hostcheck, workdir):
                                  path + ".r2", "-s", path + ".rs", "-a", "1"], capture_output=True, timeout=60)
             assert pr.returncode == 0
             assert open(path + ".r1", "rb").read() == open(os.path.join(d, name + ".out"), "rb").read(), name
+
+
+def test_output_to_a_pipe(hostcheck, workdir):
+    """-o /dev/stdout: not seekable, so no positional writes; the records still arrive in order."""
+    src = os.path.join(cu.INPUTS, "test.fastq")
+    plain = os.path.join(str(workdir), "pipe_ref.fastq")
+    assert cu.run_cli(hostcheck, workdir, ["se", "-f", src, "-t", "illumina", "-o", plain, "-a", "1", "--quiet"]).returncode == 0
+    pr = subprocess.run("%s se -f %s -t illumina -o /dev/stdout -a 1 --quiet | cat" % (hostcheck, src), shell=True,
+                        capture_output=True, timeout=120)
+    assert pr.returncode == 0
+    assert pr.stdout == open(plain, "rb").read()
