@@ -131,12 +131,40 @@ void GZReader::index_more()
             p = nl + 1;
         }
     });
+    // line table: line j of part p starts after the previous newline (the last newline of the
+    // nearest earlier non-empty part, or `begin`); the parts fill their slices concurrently
+    std::vector<size_t> first(parts + 1, 0);
+    for (size_t p = 0; p < parts; ++p) first[p + 1] = first[p] + found[p].size();
+    const size_t added = first[parts];
+    const size_t old_lines = idx_off.size();
+    idx_off.resize(old_lines + added);
+    idx_bytes.resize(old_lines + added);
+    std::vector<uint64_t> part_start(parts, begin);
+    {
+        uint64_t prev = begin;
+        for (size_t p = 0; p < parts; ++p) {
+            part_start[p] = prev;
+            if (!found[p].empty()) prev = found[p].back() + 1;
+        }
+    }
+    pool.parallel_for(parts, parts, [&](size_t lo, size_t hi, size_t) {
+        for (size_t p = lo; p < hi; ++p) {
+            uint64_t st = part_start[p];
+            uint64_t *off = idx_off.data() + old_lines + first[p];
+            uint32_t *len = idx_bytes.data() + old_lines + first[p];
+            const std::vector<uint64_t> &v = found[p];
+            for (size_t j = 0; j < v.size(); ++j) {
+                off[j] = st;
+                len[j] = (uint32_t)(v[j] + 1 - st);
+                st = v[j] + 1;
+            }
+        }
+    });
     size_t start = begin;
-    for (const std::vector<uint64_t> &v : found)
-        for (uint64_t nl : v) {
-            idx_off.push_back(start);
-            idx_bytes.push_back((uint32_t)(nl + 1 - start));
-            start = nl + 1;
+    for (size_t p = parts; p-- > 0;)
+        if (!found[p].empty()) {
+            start = (size_t)found[p].back() + 1;
+            break;
         }
     if (in_eof && start < end) { // the last line of a file that does not end in a newline
         idx_off.push_back(start);
@@ -185,12 +213,22 @@ Batch *GZReader::get_batch_buffering_lines()
     Batch *batch = new Batch();
     batch->line_off.assign(idx_off.begin(), idx_off.begin() + (long)keep);
     batch->line_len.resize(keep);
-    long total = 0;
-    for (size_t i = 0; i < keep; ++i) {
-        batch->line_len[i] = idx_bytes[i] - 1;
-        total += idx_bytes[i] - 1;
+    {
+        WorkerPool &pool = WorkerPool::instance();
+        const size_t parts = (size_t)pool.size();
+        std::vector<long> sums(parts, 0);
+        pool.parallel_for(keep, parts, [&](size_t lo, size_t hi, size_t part) {
+            long t = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                batch->line_len[i] = idx_bytes[i] - 1;
+                t += idx_bytes[i] - 1;
+            }
+            sums[part] = t;
+        });
+        long total = 0;
+        for (long t : sums) total += t;
+        batch->sequences_len = total;
     }
-    batch->sequences_len = total;
 
     // everything from the first carried line on stays in `pending` for the next batch
     const size_t cut = keep < idx_off.size() ? (size_t)idx_off[keep] : indexed;

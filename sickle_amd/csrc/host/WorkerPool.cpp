@@ -2,7 +2,9 @@
 
 #include <sched.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 WorkerPool &WorkerPool::instance()
 {
@@ -16,6 +18,27 @@ WorkerPool &WorkerPool::instance()
         if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
         if (n < 1) n = (int)std::thread::hardware_concurrency();
         if (n < 1) n = 1;
+        // a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) can be far below the CPUs it
+        // may be scheduled on; threads beyond the quota only get throttled
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32];
+            long period = 0;
+            if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+                const long q = atol(quota) / period;
+                if (q >= 1 && q < n) n = (int)q;
+            }
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            long q = -1, period = 0;
+            if (fscanf(g, "%ld", &q) == 1 && q > 0) {
+                if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                    if (fscanf(h, "%ld", &period) == 1 && period > 0 && q / period >= 1 && q / period < n)
+                        n = (int)(q / period);
+                    fclose(h);
+                }
+            }
+            fclose(g);
+        }
         if (n > 32) n = 32; // the stages are memory-bound long before that
         return n;
     }());
