@@ -198,10 +198,10 @@ typedef int sk_v4i __attribute__((ext_vector_type(4)));
 typedef int sk_v16i __attribute__((ext_vector_type(16)));
 typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 
-// MFMA = true (uniform-length batches with w <= 33): the window sums are taken off the vector
-// ALU.  A box filter is a banded 0/1 matrix, so for 32 windows x 32 reads
+// MFMA = true (uniform-length batches; w <= 65, i.e. every uniform length the tiled kernel takes):
+// the window sums are taken off the vector ALU.  A box filter is a banded 0/1 matrix, so for 32 windows x 32 reads
 //     S[window][read] - T = band(w)[window][pos] x Q[pos][read] + (-T)
-// is two v_mfma_i32_32x32x32_i8 (positions 32b..32b+63), exact in int32.  The B operand of a lane
+// is two v_mfma_i32_32x32x32_i8 (positions 32b..32b+63; three for w > 33), exact in int32.  The B operand of a lane
 // is 16 consecutive quality bytes of one read -- two ds_read_b64 from its LDS row, no shuffling;
 // the A operand is a per-lane constant.  The rows of `band` are permuted so that a lane's 16
 // accumulators are 16 CONSECUTIVE windows (lane half h: windows 16h..16h+15), which leaves the
@@ -261,7 +261,8 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const int wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
 
     // ---- constants of the matrix path
-    sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0};
+    sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0}, bandA2 = {0, 0, 0, 0};
+    const bool three_blocks = MFMA && wu > 33; // windows wider than 33 reach into a third 32-position block
     sk_v16i negT;
     const int half = lane >> 5;
     if (MFMA) {
@@ -271,15 +272,17 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         const int mp = lane & 31;
         const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
         const int win = 16 * hh + r;
-        union { sk_v4i v; int8_t b[16]; } f0, f1;
+        union { sk_v4i v; int8_t b[16]; } f0, f1, f2;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int k = 16 * half + t; // the position (relative to 32*b) this byte multiplies
             f0.b[t] = (int8_t)((win <= k && k < win + wu) ? 1 : 0);
             f1.b[t] = (int8_t)((win <= k + 32 && k + 32 < win + wu) ? 1 : 0);
+            f2.b[t] = (int8_t)((win <= k + 64 && k + 64 < win + wu) ? 1 : 0);
         }
         bandA0 = f0.v;
         bandA1 = f1.v;
+        bandA2 = f2.v;
         const int T = a.craw * wu;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -445,14 +448,34 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 return f;
             };
             sk_v4i q0 = load_frag(frag0), q1 = load_frag(frag1);
+            sk_v4i q0n = {0, 0, 0, 0}, q1n = {0, 0, 0, 0};
+            if (three_blocks) {
+                q0n = load_frag(frag0 + 32);
+                q1n = load_frag(frag1 + 32);
+            }
             for (int base = 0; base < nwinmax; base += 32) {
-                const sk_v4i q0n = load_frag(frag0 + base + 32), q1n = load_frag(frag1 + base + 32);
-                sk_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
-                sk_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0n, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1n, d1, 0, 0, 0);
-                q0 = q0n;
-                q1 = q1n;
+                sk_v16i d0, d1;
+                if (three_blocks) { // positions base .. base+95: w in 34..65
+                    const sk_v4i q0f = load_frag(frag0 + base + 64), q1f = load_frag(frag1 + base + 64);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0n, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1n, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA2, q0f, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA2, q1f, d1, 0, 0, 0);
+                    q0 = q0n;
+                    q1 = q1n;
+                    q0n = q0f;
+                    q1n = q1f;
+                } else { // positions base .. base+63: w <= 33
+                    const sk_v4i q0f = load_frag(frag0 + base + 32), q1f = load_frag(frag1 + base + 32);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0f, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1f, d1, 0, 0, 0);
+                    q0 = q0f;
+                    q1 = q1f;
+                }
                 uint32_t p0 = 0, p1 = 0; // 16 sign bits each, window order
 #pragma unroll
                 for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
@@ -772,9 +795,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
 {
     const bool uniform = lengths == nullptr;
     const bool has_seq = a->truncn != 0;
-    // the matrix path: one window width for the whole batch, band within two 32-position blocks
+    // the matrix path: one window width for the whole batch, band within three 32-position blocks
     const uint32_t wu = a->read_len / 10 ? a->read_len / 10 : a->read_len;
-    const bool mfma = uniform && wu <= 33 && a->read_len > 0;
+    const bool mfma = uniform && wu <= 65 && a->read_len > 0;
     const int nbuf = tile_nbuf_default();
 #define SK_GO(KERN, BUFS) launch_tile_kernel(KERN, BUFS, qual, seq, lengths, out, errword, a, cu_count, 0, stream)
     if (has_seq && nbuf == 1) {

@@ -289,11 +289,11 @@ def test_long_reads_and_tile_boundary(sk_ctx):
 
 
 def test_uniform_length_sweep(sk_ctx):
-    """Every uniform read length 1..345 (the matrix path covers w <= 33, i.e. L <= 339; beyond it
-    the vector path), at the stride the host packer would pick, three encodings, with and
-    without -x / -n, against the oracle."""
+    """Every uniform read length 1..345 and every 7th up to the tiled kernel's limit of 504 (two
+    32-position blocks per MFMA chain up to w = 33 / L = 339, three beyond), at the stride the host
+    packer would pick, three encodings, with and without -x / -n, against the oracle."""
     rng = np.random.default_rng(314)
-    for L in list(range(1, 346)):
+    for L in list(range(1, 346)) + list(range(346, 505, 7)) + [500, 503, 504]:
         n = 193  # three tiles + a partial one
         qt = ("sanger", "illumina", "solexa")[L % 3]
         lo, hi = {"sanger": (33, 74), "solexa": (59, 105), "illumina": (64, 105)}[qt]
