@@ -27,6 +27,13 @@
  *                 pointers are 16-byte aligned; any other fixed-stride batch goes through
  *                 the general kernel.  Fastest when stride/8 is ODD (152, 104, 264 ...): the
  *                 rows then spread over all LDS banks; stride/8 even still works, slower.
+ *   segmented   : tiles != NULL (offsets and lengths NULL).  The caller has grouped the reads
+ *                 by length: tile t holds `rows` (<= 64) reads of `read_len` bytes each at
+ *                 qual[byte_off + i*stride] (stride % 8 == 0, byte_off % 16 == 0), and slot
+ *                 slot0+i of out_index[] says where read i's cut goes: out[out_index[slot0+i]].
+ *                 Every tile is uniform inside, so mixed-length batches keep the fast tiled
+ *                 kernel (matrix-pipe window sums) with no padding to the longest read.
+ *                 batch->stride = the largest tile stride, n_reads = number of reads.
  * seq is only read when params->trunc_n != 0 (the N rule, src/trim.cpp:86-98) and may be
  * NULL otherwise.
  */
@@ -80,14 +87,27 @@ typedef struct {
     int32_t ch;    /* (int)(char) value, i.e. bytes >= 0x80 are negative */
 } sk_err;
 
+/* one tile of a segmented batch */
+typedef struct {
+    uint64_t byte_off; /* of the tile's first read in qual (and seq); multiple of 16 */
+    uint32_t slot0;    /* index of the tile's first read in out_index[] */
+    uint32_t stride;   /* bytes between the tile's reads; multiple of 8, <= SK_TILE_MAX_STRIDE */
+    uint16_t rows;     /* reads in this tile, 1..64 */
+    uint16_t read_len; /* their common length, <= stride */
+    uint32_t reserved; /* 0 */
+} sk_tile;
+
 typedef struct {
     const uint8_t *qual;
     const uint8_t *seq;      /* NULL unless trunc_n */
     const uint64_t *offsets; /* n_reads+1 entries, or NULL */
-    uint32_t stride;         /* fixed-stride layout only */
+    uint32_t stride;         /* fixed-stride layout; segmented: the largest tile stride */
     uint32_t read_len;       /* fixed-stride layout with lengths == NULL */
     const uint32_t *lengths; /* fixed-stride layout, per-read lengths, or NULL */
     uint64_t n_reads;
+    const sk_tile *tiles;      /* segmented layout: n_tiles descriptors, or NULL */
+    uint32_t n_tiles;
+    const uint32_t *out_index; /* segmented layout: n_reads entries */
 } sk_batch;
 
 typedef struct sk_ctx sk_ctx;
@@ -145,7 +165,7 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
 int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile),
- * 2 = general (wave per read).  For tests and bench labels. */
+ * 2 = general (wave per read), 3 = tiled over a segmented batch.  For tests and bench labels. */
 int sk_kernel_for(const sk_batch *batch);
 
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */

@@ -28,9 +28,19 @@ class Err(C.Structure):
     _fields_ = [("read", C.c_uint32), ("pos", C.c_uint32), ("ch", C.c_int32)]
 
 
+class Tile(C.Structure):
+    _fields_ = [("byte_off", C.c_uint64), ("slot0", C.c_uint32), ("stride", C.c_uint32), ("rows", C.c_uint16),
+                ("read_len", C.c_uint16), ("reserved", C.c_uint32)]
+
+
+TILE_DTYPE = np.dtype([("byte_off", "<u8"), ("slot0", "<u4"), ("stride", "<u4"), ("rows", "<u2"), ("read_len", "<u2"),
+                       ("reserved", "<u4")])
+
+
 class Batch(C.Structure):
     _fields_ = [("qual", C.c_void_p), ("seq", C.c_void_p), ("offsets", C.c_void_p), ("stride", C.c_uint32),
-                ("read_len", C.c_uint32), ("lengths", C.c_void_p), ("n_reads", C.c_uint64)]
+                ("read_len", C.c_uint32), ("lengths", C.c_void_p), ("n_reads", C.c_uint64),
+                ("tiles", C.c_void_p), ("n_tiles", C.c_uint32), ("out_index", C.c_void_p)]
 
 
 class SickleError(RuntimeError):
@@ -137,6 +147,22 @@ class Context:
         raise SickleError("libsickle_amd call failed (%d): %s" % (rc, lib().sk_last_error(self._h).decode()))
 
     # ---- host buffers (numpy) -------------------------------------------------------------
+    def trim_segmented(self, params, qual, tiles, out_index, max_stride, seq=None):
+        """sk_trim_batch on a segmented batch (tiles: numpy array of TILE_DTYPE) -> cuts[n,2] int32
+        in the caller's read order (out_index)."""
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        seq = None if seq is None else np.ascontiguousarray(seq, dtype=np.uint8)
+        tiles = np.ascontiguousarray(tiles, dtype=TILE_DTYPE)
+        out_index = np.ascontiguousarray(out_index, dtype=np.uint32)
+        n = len(out_index)
+        out = np.full((n, 2), -7, dtype=np.int32)
+        b = Batch(_np_ptr(qual), _np_ptr(seq), None, max_stride, 0, None, n, tiles.ctypes.data, len(tiles),
+                  out_index.ctypes.data)
+        err = Err()
+        rc = lib().sk_trim_batch(self._h, C.byref(params), C.byref(b), out.ctypes.data, C.byref(err))
+        self._check(rc, err)
+        return out
+
     def trim_batch(self, params, qual, seq=None, offsets=None, stride=0, read_len=0, lengths=None, n_reads=None):
         """sk_trim_batch on numpy host arrays -> cuts[n,2] int32.  Raises RangeError like the
         reference exits."""

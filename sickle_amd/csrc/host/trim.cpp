@@ -223,10 +223,11 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     const int dev_slot = slot / (int)ctxs.size();
     const size_t n = reads.size();
     // Layout.  Equal-length batches (the usual case): fixed stride, uniform length -> the tiled
-    // kernel with the matrix-pipe window sums.  Mixed lengths up to SK_TILE_MAX_STRIDE: the same
-    // fixed stride (padded to the longest read) plus a per-read length array -> the tiled kernel's
-    // vector path, which is ~8x the rate of the general kernel; the padding only costs PCIe bytes,
-    // and PCIe is two orders of magnitude ahead of the host parser.  Anything longer: packed back
+    // kernel with the matrix-pipe window sums.  Mixed lengths up to the tiled kernel's limit: the
+    // reads are grouped by length (counting sort) into tiles of <= 64 equal-length rows, each group
+    // at its own stride, described to the device by one sk_tile per tile; every tile is uniform
+    // inside, so the batch stays on the same fast path with no padding to the longest read, and
+    // the device scatters the cuts back to input order (out_index).  Anything longer: packed back
     // to back with an offsets array -> the general (wave-per-read) kernel.
     size_t total_len = 0, max_len = 0;
     bool uniform = true;
@@ -240,32 +241,78 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     // stride: a multiple of 8 with an ODD number of 8-byte units, so that the per-lane row walks of
     // the tiled kernel (ds_read_b64 at lane*stride) spread over all LDS banks; an even count
     // (e.g. 250 -> 256) puts every lane on the same banks (measured: 2.6x slower)
-    size_t stride8 = (max_len + 7) / 8;
-    if (stride8 % 2 == 0) ++stride8;
-    const bool tiled = n > 0 && max_len > 0 && stride8 * 8 <= SK_TILE_MAX_STRIDE;
-    const size_t stride = tiled ? stride8 * 8 : 0;
-    const size_t bytes = tiled ? n * stride : total_len;
+    auto stride_for = [](size_t len) {
+        size_t s8 = (len + 7) / 8;
+        if (s8 % 2 == 0) ++s8;
+        return s8 * 8;
+    };
+    const bool tiled = n > 0 && max_len > 0 && stride_for(max_len) <= SK_TILE_MAX_STRIDE;
+    const bool segmented = tiled && !uniform;
     const bool need_seq = trunc_n != 0;
-    grow(ctx, s, bytes, n, need_seq);
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = (size_t)pool.size() * 4;
 
     sk_batch b;
     memset(&b, 0, sizeof b);
-    WorkerPool &pool = WorkerPool::instance();
-    const size_t parts = (size_t)pool.size() * 4;
-    if (tiled) {
-        uint32_t *lengths = reinterpret_cast<uint32_t *>(s.offsets); // the index buffer holds either
+    if (segmented) {
+        // group g = reads of length g: first slot, byte offset of its first tile, stride
+        std::vector<uint32_t> first_slot(max_len + 2, 0);
+        for (const FQEntry &r : reads) first_slot[r.qual.length() + 1]++;
+        for (size_t l = 0; l <= max_len; ++l) first_slot[l + 1] += first_slot[l];
+        std::vector<uint64_t> group_off(max_len + 1, 0);
+        s.tiles.clear();
+        uint64_t at = 0;
+        for (size_t l = 1; l <= max_len; ++l) {
+            const uint32_t cnt = first_slot[l + 1] - first_slot[l];
+            if (!cnt) continue;
+            const uint32_t st = (uint32_t)stride_for(l);
+            at = (at + 15) & ~(uint64_t)15;
+            group_off[l] = at;
+            for (uint32_t a0 = 0; a0 < cnt; a0 += 64) {
+                sk_tile t;
+                t.byte_off = at + (uint64_t)a0 * st;
+                t.slot0 = first_slot[l] + a0;
+                t.stride = st;
+                t.rows = (uint16_t)std::min<uint32_t>(64, cnt - a0);
+                t.read_len = (uint16_t)l;
+                t.reserved = 0;
+                s.tiles.push_back(t);
+            }
+            at += (uint64_t)cnt * st;
+        }
+        grow(ctx, s, (size_t)at, n, need_seq);
+        // slot of every read (stable within a length), then the copies, on the pool
+        uint32_t *out_index = reinterpret_cast<uint32_t *>(s.offsets); // the index buffer holds either
+        std::vector<uint32_t> next = first_slot;
+        std::vector<uint32_t> slot_of(n);
+        for (size_t i = 0; i < n; ++i) slot_of[i] = next[reads[i].qual.length()]++;
         pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
             for (size_t i = lo; i < hi; ++i) {
                 const size_t l = reads[i].qual.length();
-                memcpy(s.qual + i * stride, reads[i].qual.data(), l);
-                if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), l);
-                if (!uniform) lengths[i] = (uint32_t)l;
+                const uint32_t slot = slot_of[i];
+                const uint64_t dst = group_off[l] + (uint64_t)(slot - first_slot[l]) * stride_for(l);
+                memcpy(s.qual + dst, reads[i].qual.data(), l);
+                if (need_seq) memcpy(s.seq + dst, reads[i].seq.data(), l);
+                out_index[slot] = (uint32_t)i;
+            }
+        });
+        b.stride = (uint32_t)stride_for(max_len);
+        b.tiles = s.tiles.data();
+        b.n_tiles = (uint32_t)s.tiles.size();
+        b.out_index = out_index;
+    } else if (tiled) {
+        const size_t stride = stride_for(len0);
+        grow(ctx, s, n * stride, n, need_seq);
+        pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; ++i) {
+                memcpy(s.qual + i * stride, reads[i].qual.data(), len0);
+                if (need_seq) memcpy(s.seq + i * stride, reads[i].seq.data(), len0);
             }
         });
         b.stride = (uint32_t)stride;
         b.read_len = (uint32_t)len0;
-        b.lengths = uniform ? nullptr : lengths;
     } else {
+        grow(ctx, s, total_len, n, need_seq);
         size_t at = 0;
         for (size_t i = 0; i < n; ++i) {
             s.offsets[i] = at;

@@ -191,6 +191,7 @@ private:
         uint64_t *offsets = nullptr;
         sk_cut *cuts = nullptr;
         size_t cap_reads = 0;
+        std::vector<sk_tile> tiles; // segmented batches: one descriptor per tile
     };
     std::vector<int> device_ids; // set by open_device() before it returns
     std::vector<sk_ctx *> ctxs;  // one per entry of device_ids, created by the opener thread

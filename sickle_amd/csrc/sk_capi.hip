@@ -13,6 +13,8 @@
 #include "sickle_amd.h"
 #include "sk_device.h"
 
+static_assert(sizeof(sk_tile) == sizeof(sk_tile_dev) && sizeof(sk_tile) == 24, "sk_tile layout");
+
 namespace {
 
 // reference src/sickle.h:85-91
@@ -34,6 +36,9 @@ struct Slot {
     uint64_t *d_offsets = nullptr;
     uint32_t *d_lengths = nullptr;
     size_t cap_reads = 0;
+    sk_tile_dev *d_tiles = nullptr;
+    uint32_t *d_out_index = nullptr;
+    size_t cap_tiles = 0, cap_index = 0;
     sk_cut_dev *d_out = nullptr;
     unsigned long long *d_err = nullptr; // device error word of this slot
     unsigned long long *h_err = nullptr; // pinned copy
@@ -92,7 +97,14 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
         set_error(ctx, "trunc_n needs seq");
         return SK_EINVAL;
     }
-    if (!b->offsets) {
+    if (b->tiles) {
+        if (b->offsets || b->lengths || !b->out_index || b->n_tiles == 0 || b->stride % 8 != 0 ||
+            b->stride > SK_TILE_MAX_STRIDE || b->stride == 0) {
+            set_error(ctx, "segmented batch: need tiles, out_index, n_tiles and the largest stride (multiple of 8, <= %u)",
+                      SK_TILE_MAX_STRIDE);
+            return SK_EINVAL;
+        }
+    } else if (!b->offsets) {
         if (b->stride == 0 || (!b->lengths && b->read_len > b->stride)) {
             set_error(ctx, "fixed-stride batch: need stride >= read_len > 0");
             return SK_EINVAL;
@@ -118,6 +130,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->lthr = p->length_threshold;
     a->no5 = p->no_fiveprime ? 1 : 0;
     a->truncn = p->trunc_n ? 1 : 0;
+    a->n_tiles = b->tiles ? b->n_tiles : 0;
     static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
     a->tile_order = order;
     return SK_OK;
@@ -125,7 +138,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
 
 bool tile_eligible(const sk_batch *b)
 {
-    return !b->offsets && b->stride % 8 == 0 && b->stride >= 8 && b->stride <= SK_TILE_MAX_STRIDE &&
+    return !b->offsets && !b->tiles && b->stride % 8 == 0 && b->stride >= 8 && b->stride <= SK_TILE_MAX_STRIDE &&
            (reinterpret_cast<uintptr_t>(b->qual) & 15) == 0 && (!b->seq || (reinterpret_cast<uintptr_t>(b->seq) & 15) == 0);
 }
 
@@ -137,7 +150,10 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
 {
     if (a->n_reads == 0) return SK_OK;
     const uint8_t *seq = a->truncn ? b->seq : nullptr;
-    if (tile_eligible(b))
+    if (b->tiles)
+        SK_HIP(ctx, sk_launch_seg(b->qual, seq, reinterpret_cast<const sk_tile_dev *>(b->tiles), b->out_index, out, d_err, a,
+                                  ctx->cu_count, stream));
+    else if (tile_eligible(b))
         SK_HIP(ctx, sk_launch_tile(b->qual, seq, b->lengths, out, d_err, a, ctx->cu_count, stream));
     else
         SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, a, ctx->cu_count, stream));
@@ -165,6 +181,10 @@ size_t batch_bytes(const sk_batch *b)
 {
     // bytes of qual (and seq) the batch spans on the host
     if (b->n_reads == 0) return 0;
+    if (b->tiles) {
+        const sk_tile &last = b->tiles[b->n_tiles - 1];
+        return (size_t)last.byte_off + (size_t)last.rows * last.stride;
+    }
     if (b->offsets) return (size_t)b->offsets[b->n_reads];
     return (size_t)b->n_reads * b->stride;
 }
@@ -285,6 +305,8 @@ void sk_destroy(sk_ctx *ctx)
         if (s.d_seq) (void)hipFree(s.d_seq);
         if (s.d_offsets) (void)hipFree(s.d_offsets);
         if (s.d_lengths) (void)hipFree(s.d_lengths);
+        if (s.d_tiles) (void)hipFree(s.d_tiles);
+        if (s.d_out_index) (void)hipFree(s.d_out_index);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_err) (void)hipFree(s.d_err);
         if (s.h_err) (void)hipHostFree(s.h_err);
@@ -322,6 +344,7 @@ void sk_host_free(sk_ctx *ctx, void *p)
 int sk_kernel_for(const sk_batch *batch)
 {
     if (!batch) return 0;
+    if (batch->tiles) return 3;
     return tile_eligible(batch) ? 1 : 2;
 }
 
@@ -330,6 +353,7 @@ const char *sk_kernel_name(int which)
     switch (which) {
     case 1: return "sk_scan_tile_kernel";
     case 2: return "sk_scan_wave_kernel";
+    case 3: return "sk_scan_tile_kernel";
     default: return "";
     }
 }
@@ -377,6 +401,48 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
     }
     rc = grow_slot(ctx, s, bytes, n, a.truncn != 0, batch->offsets != nullptr, batch->lengths != nullptr);
     if (rc != SK_OK) return rc;
+    if (batch->tiles) {
+        // descriptors are checked here, on the host, before any of them reaches a kernel
+        uint64_t reads = 0;
+        for (uint32_t t = 0; t < batch->n_tiles; ++t) {
+            const sk_tile &d = batch->tiles[t];
+            if (d.rows == 0 || d.rows > 64 || d.stride % 8 != 0 || d.stride > batch->stride || d.read_len > d.stride ||
+                d.byte_off % 16 != 0 || (size_t)d.byte_off + (size_t)d.rows * d.stride > bytes ||
+                (uint64_t)d.slot0 + d.rows > batch->n_reads) {
+                set_error(ctx, "segmented batch: tile %u is malformed", t);
+                return SK_EINVAL;
+            }
+            reads += d.rows;
+        }
+        if (reads != batch->n_reads) {
+            set_error(ctx, "segmented batch: tiles hold %llu reads, n_reads is %llu", (unsigned long long)reads,
+                      (unsigned long long)batch->n_reads);
+            return SK_EINVAL;
+        }
+        for (size_t i = 0; i < n; ++i)
+            if (batch->out_index[i] >= batch->n_reads) {
+                set_error(ctx, "segmented batch: out_index[%zu] out of range", i);
+                return SK_EINVAL;
+            }
+        if (batch->n_tiles > s.cap_tiles) {
+            if (s.d_tiles) (void)hipFree(s.d_tiles);
+            s.d_tiles = nullptr;
+            s.cap_tiles = 0;
+            const size_t cap = batch->n_tiles + (batch->n_tiles >> 3) + 16;
+            SK_HIP(ctx, hipMalloc(&s.d_tiles, cap * sizeof(sk_tile_dev)));
+            s.cap_tiles = cap;
+        }
+        if (n > s.cap_index) {
+            if (s.d_out_index) (void)hipFree(s.d_out_index);
+            s.d_out_index = nullptr;
+            s.cap_index = 0;
+            const size_t cap = n + (n >> 3) + 16;
+            SK_HIP(ctx, hipMalloc(&s.d_out_index, cap * sizeof(uint32_t)));
+            s.cap_index = cap;
+        }
+        SK_HIP(ctx, hipMemcpyAsync(s.d_tiles, batch->tiles, batch->n_tiles * sizeof(sk_tile), hipMemcpyHostToDevice, ctx->copy));
+        SK_HIP(ctx, hipMemcpyAsync(s.d_out_index, batch->out_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy));
+    }
 
     // H2D on the copy stream (overlaps the previous slot's kernel on the compute stream)
     if (bytes) {
@@ -395,6 +461,8 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
     dev.seq = a.truncn ? s.d_seq : nullptr;
     dev.offsets = batch->offsets ? s.d_offsets : nullptr;
     dev.lengths = (!batch->offsets && batch->lengths) ? s.d_lengths : nullptr;
+    dev.tiles = batch->tiles ? reinterpret_cast<const sk_tile *>(s.d_tiles) : nullptr;
+    dev.out_index = batch->tiles ? s.d_out_index : nullptr;
     rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute);
     if (rc != SK_OK) return rc;
     if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));

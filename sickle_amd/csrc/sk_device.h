@@ -16,6 +16,16 @@ struct sk_cut_dev {
     int32_t five, three;
 };
 
+// == sk_tile of the C ABI (include/sickle_amd.h)
+struct sk_tile_dev {
+    uint64_t byte_off;
+    uint32_t slot0;
+    uint32_t stride;
+    uint16_t rows;
+    uint16_t read_len;
+    uint32_t reserved;
+};
+
 // Scalar arguments of one scan, derived on the host from sk_params (+ the batch shape).
 struct sk_scan_args {
     uint64_t n_reads;
@@ -28,6 +38,7 @@ struct sk_scan_args {
     int32_t lthr;      // length_threshold
     int32_t no5;       // -x
     int32_t truncn;    // -n
+    uint32_t n_tiles;   // segmented batches: number of tile descriptors
     int32_t tile_order; // diagnostic (SK_TILE_ORDER): 0 = tile t on workgroup t mod G, 1 = contiguous tile ranges per XCD
 };
 
@@ -35,6 +46,9 @@ struct sk_scan_args {
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const uint8_t *qual, const uint8_t *seq, const sk_tile_dev *tiles,
+                                    const uint32_t *out_index, sk_cut_dev *out, unsigned long long *errword,
+                                    const sk_scan_args *a, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                      const sk_scan_args *a, int cu_count, hipStream_t stream);

@@ -217,13 +217,20 @@ typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 //
 // ABLATE (diagnostic launches of tools/ablate.py only; the product always runs 0):
 //   1 = DMA + cut store only (no scan), 2 = scan only (tile loaded once, then reused)
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0>
+//
+// SEG = segmented batches (mixed lengths, sorted by length on the host): every tile has its own
+// descriptor -- byte offset, row stride, read length, row count -- and is uniform inside, so it
+// takes the matrix path like a uniform batch (the band matrix is rebuilt when the length changes,
+// which in a sorted batch is rare); cuts are scattered to out[out_index[slot]].
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0, bool SEG = false>
 __global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
-                    unsigned long long *errword, sk_scan_args a)
+                    unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
+                    const uint32_t *__restrict__ out_index = nullptr)
 {
     static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
+    static_assert(!SEG || (UNIFORM && MFMA && NBUF == 1), "segmented batches run the uniform matrix path, one buffer");
     // -n: NBUF == 2 keeps the quality and the sequence tile in two buffers (8 waves per CU);
     // NBUF == 1 runs both through ONE buffer, one after the other (16 waves per CU)
     constexpr int LDS_BUFS = NBUF;
@@ -235,12 +242,12 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     // SGPRs and branch on the scalar unit instead of being carried through the vector ALU
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int waves_per_block = blockDim.x >> 6;
-    const uint32_t stride = a.stride;
+    const uint32_t stride = a.stride; // SEG: the largest row stride of the batch (sizes the LDS buffers)
     const uint32_t buf_bytes = 64u * stride + SK_TILE_SLACK;
     uint8_t *buf0 = lds + (size_t)wave * LDS_BUFS * buf_bytes;
     uint8_t *buf1 = LDS_BUFS > 1 ? buf0 + buf_bytes : buf0;
 
-    const uint64_t n_tiles = (a.n_reads + 63) >> 6;
+    const uint64_t n_tiles = SEG ? (uint64_t)a.n_tiles : (a.n_reads + 63) >> 6;
     uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
     const uint64_t wave_count = (uint64_t)gridDim.x * waves_per_block;
     if (a.tile_order == 1 && (wave_count & 7) == 0) {
@@ -255,56 +262,62 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const uint32_t cthr4 = splat((uint32_t)a.cthr);
     const int range = a.qmax - a.qmin;
 
-    // uniform-length batches: one length, one window width, one window count for every lane
-    const int Lu = (int)a.read_len;
-    const bool scan_u = Lu > 0 && Lu >= a.lthr; // reference trim.cpp:21
-    const int wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
-
-    // ---- constants of the matrix path
+    // uniform-length batches (and each tile of a segmented one): one length, one window width, one
+    // window count for every lane
+    int Lu = 0, wu = 0;
+    bool scan_u = false, three_blocks = false;
     sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0}, bandA2 = {0, 0, 0, 0};
-    const bool three_blocks = MFMA && wu > 33; // windows wider than 33 reach into a third 32-position block
     sk_v16i negT;
     const int half = lane >> 5;
-    if (MFMA) {
-        // this lane supplies row m' = lane&31 of A; the hardware puts row m' into accumulator
-        // reg r of lane half hh with m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be
-        // window 16*hh + r
-        const int mp = lane & 31;
-        const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
-        const int win = 16 * hh + r;
-        union { sk_v4i v; int8_t b[16]; } f0, f1, f2;
+    auto set_length = [&](int len) {
+        Lu = len;
+        scan_u = Lu > 0 && Lu >= a.lthr;  // reference trim.cpp:21
+        wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
+        three_blocks = MFMA && wu > 33;   // windows wider than 33 reach into a third 32-position block
+        if (MFMA) {
+            // ---- constants of the matrix path.  This lane supplies row m' = lane&31 of A; the
+            // hardware puts row m' into accumulator reg r of lane half hh with
+            // m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be window 16*hh + r
+            const int mp = lane & 31;
+            const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
+            const int win = 16 * hh + r;
+            union { sk_v4i v; int8_t b[16]; } f0, f1, f2;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int k = 16 * half + t; // the position (relative to 32*b) this byte multiplies
-            f0.b[t] = (int8_t)((win <= k && k < win + wu) ? 1 : 0);
-            f1.b[t] = (int8_t)((win <= k + 32 && k + 32 < win + wu) ? 1 : 0);
-            f2.b[t] = (int8_t)((win <= k + 64 && k + 64 < win + wu) ? 1 : 0);
-        }
-        bandA0 = f0.v;
-        bandA1 = f1.v;
-        bandA2 = f2.v;
-        const int T = a.craw * wu;
+            for (int t = 0; t < 16; ++t) {
+                const int k = 16 * half + t; // the position (relative to 32*b) this byte multiplies
+                f0.b[t] = (int8_t)((win <= k && k < win + wu) ? 1 : 0);
+                f1.b[t] = (int8_t)((win <= k + 32 && k + 32 < win + wu) ? 1 : 0);
+                f2.b[t] = (int8_t)((win <= k + 64 && k + 64 < win + wu) ? 1 : 0);
+            }
+            bandA0 = f0.v;
+            bandA1 = f1.v;
+            bandA2 = f2.v;
+            const int T = a.craw * wu;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int seed = -T;
-            // opaque to the compiler: otherwise it keeps this uniform value in SGPRs and copies it
-            // into 16 VGPRs again before every MFMA pair (8 v_mov_b64 per 32 windows)
-            asm volatile("" : "+v"(seed));
-            negT[i] = seed;
+            for (int i = 0; i < 16; ++i) {
+                int seed = -T;
+                // opaque to the compiler: otherwise it keeps this uniform value in SGPRs and copies
+                // it into 16 VGPRs again before every MFMA pair (8 v_mov_b64 per 32 windows)
+                asm volatile("" : "+v"(seed));
+                negT[i] = seed;
+            }
         }
-    }
+    };
+    if (!SEG) set_length((int)a.read_len);
 
     auto tile_bytes_of = [&](uint64_t t) -> uint32_t {
+        if (SEG) return (uint32_t)tiles[t].rows * tiles[t].stride;
         return (uint32_t)min((uint64_t)64, a.n_reads - (t << 6)) * stride;
     };
+    auto tile_off_of = [&](uint64_t t) -> uint64_t { return SEG ? tiles[t].byte_off : (t << 6) * stride; };
 
     uint64_t t = wave_global;
     if (t >= n_tiles) return;
 
     // prologue: Q(t) [and S(t)] in flight
     uint32_t cur_bytes = tile_bytes_of(t);
-    tile_to_lds(qual + (t << 6) * stride, buf0, cur_bytes, lane);
-    if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + (t << 6) * stride, buf1, cur_bytes, lane);
+    tile_to_lds(qual + tile_off_of(t), buf0, cur_bytes, lane);
+    if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + tile_off_of(t), buf1, cur_bytes, lane);
     int len_next = 0;
     if (!UNIFORM) {
         const uint64_t r = (t << 6) + lane;
@@ -314,14 +327,23 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 
     for (; t < n_tiles; t += wave_count) {
         const uint64_t r0 = t << 6;
-        const uint64_t r = r0 + lane;
+        uint32_t ts = stride; // this tile's row stride
+        uint32_t seg_rows = 64;
+        if (SEG) {
+            const sk_tile_dev d = tiles[t];
+            ts = d.stride;
+            seg_rows = d.rows;
+            if ((int)d.read_len != Lu) set_length((int)d.read_len);
+        }
+        // where this lane's cut goes: segmented batches scatter back to the caller's read order
+        const uint64_t r = SEG ? (uint64_t)out_index[tiles[t].slot0 + min((uint32_t)lane, seg_rows - 1u)] : r0 + lane;
         const uint64_t tn = t + wave_count;
         const bool more = tn < n_tiles;
         const uint32_t next_bytes = more ? tile_bytes_of(tn) : 0u;
         const int next_pieces = more ? tile_pieces(next_bytes) : 0;
         const uint8_t *tile;
 
-        const bool active = r < a.n_reads;
+        const bool active = SEG ? (uint32_t)lane < seg_rows : r < a.n_reads;
         int Lv = 0; // mixed lengths: this lane's length
         if (!UNIFORM) {
             if (active) Lv = len_next;
@@ -344,15 +366,15 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         } else {
             tile = parity ? buf1 : buf0;
             uint8_t *other = parity ? buf0 : buf1;
-            if (more) tile_to_lds(qual + (tn << 6) * stride, other, next_bytes, lane);
+            if (more) tile_to_lds(qual + tile_off_of(tn), other, next_bytes, lane);
             wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
             parity ^= 1;
         }
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * stride);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * ts);
         if (ABLATE == 1) {
             const sk_cut_dev dummy{(int)row[0], (int)row[1]};
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (NBUF == 1 && more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+            if (NBUF == 1 && more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
             if (active) out[r] = dummy;
             cur_bytes = next_bytes;
             continue;
@@ -439,8 +461,8 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 
         if (MFMA) {
             // lane (n = lane&31, half): 16 bytes of read 32g+n at positions 32*kb + 16*half
-            const uint8_t *frag0 = tile + (size_t)(lane & 31) * stride + 16 * half;
-            const uint8_t *frag1 = frag0 + (size_t)32 * stride;
+            const uint8_t *frag0 = tile + (size_t)(lane & 31) * ts + 16 * half;
+            const uint8_t *frag1 = frag0 + (size_t)32 * ts;
             auto load_frag = [](const uint8_t *p) -> sk_v4i {
                 const uint64_t lo = *reinterpret_cast<const uint64_t *>(p);
                 const uint64_t hi = *reinterpret_cast<const uint64_t *>(p + 8);
@@ -564,7 +586,7 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                     uint32_t f = keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
                     if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
                 }
-                if (p < touched) report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * stride + p]));
+                if (p < touched) report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
             }
         }
 
@@ -573,14 +595,14 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (SEQ_SHARES) {
                 // the quality scan is over: the same buffer now takes the sequence tile of these reads
-                tile_to_lds(seq + r0 * stride, buf0, cur_bytes, lane);
+                tile_to_lds(seq + tile_off_of(t), buf0, cur_bytes, lane);
                 wait_vmcnt(0);
             } else {
                 // buf0 is free now: start Q(t+1), then retire S(t)
-                if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+                if (more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
                 wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
             }
-            const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)lane * stride);
+            const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)lane * ts);
             // 'n' (0x6e) and 'N' (0x4e) differ in bit 5 only: one zero-byte test on (c | 0x20) ^ 'n'
             // flags both, bit 5 of the original byte tells them apart.  nlo = bit index of the first
             // lowercase n (NONE if none), anyN = whether an uppercase N occurs at all.
@@ -616,14 +638,14 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) {
-                if (SEQ_SHARES) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane); // Q(t+1)
-                else tile_to_lds(seq + (tn << 6) * stride, buf1, next_bytes, lane);             // S(t+1)
+                if (SEQ_SHARES) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane); // Q(t+1)
+                else tile_to_lds(seq + tile_off_of(tn), buf1, next_bytes, lane);             // S(t+1)
             }
         } else if (NBUF == 1 && ABLATE != 2) {
             // single buffer: every LDS read of this tile is done, refill it now -- the cut store
             // below and the other waves of the CU cover the DMA latency
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) tile_to_lds(qual + (tn << 6) * stride, buf0, next_bytes, lane);
+            if (more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
         }
 #if SK_TAIL_PRIO
         __builtin_amdgcn_s_setprio(0);
@@ -783,7 +805,8 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, lengths, out, errword, *a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, lengths, out, errword, *a,
+                       (const sk_tile_dev *)nullptr, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -819,6 +842,30 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
     if (uniform) return SK_GO((sk_scan_tile_kernel<true, false, false, 2>), 2);
     return SK_GO((sk_scan_tile_kernel<false, false, false, 2>), 2);
 #undef SK_GO
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const uint8_t *qual, const uint8_t *seq, const sk_tile_dev *tiles,
+                                    const uint32_t *out_index, sk_cut_dev *out, unsigned long long *errword,
+                                    const sk_scan_args *a, int cu_count, hipStream_t stream)
+{
+    // a->stride = the largest row stride of the batch: sizes the one LDS buffer of each wave
+    const uint32_t lds_bytes = 64u * a->stride + SK_TILE_SLACK;
+    if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    if (per_cu > 16) per_cu = 16;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    if (grid > a->n_tiles) grid = a->n_tiles;
+    if (grid == 0) return hipSuccess;
+    auto launch = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq,
+                           (const uint32_t *)nullptr, out, errword, *a, tiles, out_index);
+        return hipGetLastError();
+    };
+    if (a->truncn) return launch(sk_scan_tile_kernel<true, true, true, 1, 0, true>);
+    return launch(sk_scan_tile_kernel<true, false, true, 1, 0, true>);
 }
 
 // diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py).

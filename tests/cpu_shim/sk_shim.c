@@ -55,6 +55,27 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *p, const sk_batch *b, sk_c
     sko_params op = {p->qualtype, p->qual_threshold, p->length_threshold, p->no_fiveprime, p->trunc_n};
     sko_err e = {0, 0, 0};
     if (ctx->busy[slot]) return SK_EBUSY;
+    if (b->tiles) { /* segmented layout: read by read through the oracle, lowest output index wins on error */
+        uint32_t t, i, best = 0xffffffffu;
+        ctx->rc[slot] = 0;
+        for (t = 0; t < b->n_tiles; ++t) {
+            const sk_tile *d = &b->tiles[t];
+            for (i = 0; i < d->rows; ++i) {
+                const uint64_t off = d->byte_off + (uint64_t)i * d->stride;
+                const uint32_t dst = b->out_index[d->slot0 + i];
+                sko_err e1 = {0, 0, 0};
+                if (sko_sliding_window(&op, b->seq ? b->seq + off : NULL, b->qual + off, d->read_len,
+                                       (sko_cut *)&out[dst], &e1)) {
+                    ctx->rc[slot] = 1;
+                    if (dst < best) {
+                        best = dst;
+                        e = e1;
+                        e.read = dst;
+                    }
+                }
+            }
+        }
+    } else
     ctx->rc[slot] = sko_trim_batch(&op, b->qual, b->seq, b->offsets, b->stride, b->read_len, b->lengths, b->n_reads,
                                    (sko_cut *)out, &e);
     ctx->err[slot].read = e.read;

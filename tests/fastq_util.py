@@ -28,3 +28,46 @@ def emit_records(records, cuts):
         if three >= 0:
             out.append(name + b"\n" + seq[five:three] + b"\n" + comment + b"\n" + qual[five:three] + b"\n")
     return b"".join(out)
+
+
+def segment_by_length(seq, qual, offsets):
+    """ragged -> the segmented C-ABI layout: reads grouped by length into tiles of <= 64 rows, each
+    tile at its own stride (multiple of 8 with an odd number of 8-byte units).
+    Returns (seq_bytes, qual_bytes, tiles[TILE_DTYPE], out_index, max_stride)."""
+    from sickle_amd.capi import TILE_DTYPE
+    lens = np.diff(offsets).astype(np.int64)
+    order = np.argsort(lens, kind="stable")
+    tiles = []
+    qb, sb = [], []
+    at = 0
+    slot = 0
+    i = 0
+    n = len(order)
+    max_stride = 8
+    while i < n:
+        L = int(lens[order[i]])
+        j = i
+        while j < n and lens[order[j]] == L:
+            j += 1
+        stride = ((L + 7) // 8 | 1) * 8
+        max_stride = max(max_stride, stride)
+        for a in range(i, j, 64):
+            rows = min(64, j - a)
+            pad = (-at) % 16
+            if pad:
+                qb.append(np.zeros(pad, dtype=np.uint8))
+                sb.append(np.zeros(pad, dtype=np.uint8))
+                at += pad
+            qm = np.zeros((rows, stride), dtype=np.uint8)
+            sm = np.zeros((rows, stride), dtype=np.uint8)
+            for k in range(rows):
+                o = int(offsets[order[a + k]])
+                qm[k, :L] = qual[o:o + L]
+                sm[k, :L] = seq[o:o + L]
+            qb.append(qm.reshape(-1))
+            sb.append(sm.reshape(-1))
+            tiles.append((at, slot, stride, rows, L, 0))
+            at += rows * stride
+            slot += rows
+        i = j
+    return (np.concatenate(sb), np.concatenate(qb), np.array(tiles, dtype=TILE_DTYPE), order.astype(np.uint32), max_stride)

@@ -315,3 +315,31 @@ def test_uniform_length_sweep(sk_ctx):
         got = sk_ctx.trim_batch(p, qs, ss, stride=stride, read_len=L, n_reads=n)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert bad.size == 0, (L, qt, q, l, x, tn, bad[:4], got[bad[:4]], want[bad[:4]])
+
+
+def test_segmented_batches(sk_ctx):
+    """Mixed lengths grouped by length into per-tile descriptors (the layout the CLI uses for
+    mixed-length files): the tiled kernel's matrix path tile by tile, cuts scattered back to the
+    caller's order, against the oracle on the ragged original.  Includes -n, -x, lengths below
+    -l, and an out-of-range char whose read index must come back in the caller's numbering."""
+    from fastq_util import segment_by_length
+    seq, qual, offsets = synth.make_ragged_reads(17, 30_000, 1, 330, "illumina", lower_n_frac=0.02)
+    ss, qs, tiles, out_index, max_stride = segment_by_length(seq, qual, offsets)
+    assert len(out_index) == 30_000 and tiles["rows"].sum() == 30_000
+    for q, l, x, tn in ((20, 20, 0, 0), (22, 50, 0, 1), (20, 0, 1, 1)):
+        p, po = both_params("illumina", q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offsets, threads=4)
+        assert err is None
+        got = sk_ctx.trim_segmented(p, qs, tiles, out_index, max_stride, seq=ss)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], np.diff(offsets)[bad[:5]])
+    # range error: reported with the ORIGINAL read index, lowest original index first
+    q2 = qual.copy()
+    victims = [25_000, 7_777]
+    for v in victims:
+        q2[int(offsets[v]) + 3] = 20
+    ss2, qs2, tiles2, oi2, ms2 = segment_by_length(seq, q2, offsets)
+    p, _ = both_params("illumina", 20, 0, 0, 0)
+    with pytest.raises(capi.RangeError) as ei:
+        sk_ctx.trim_segmented(p, qs2, tiles2, oi2, ms2, seq=ss2)
+    assert (ei.value.read, ei.value.pos, ei.value.ch) == (7_777, 3, 20)

@@ -59,3 +59,31 @@ q100 = bench.synth_quals_device(torch, n, 100, 104, 3, dev)
 torch.cuda.synchronize()
 report("tile+mfma uniform 100 (stride 104)", timeit(lambda: ctx.scan_device_async(p, q100.data_ptr(), out.data_ptr(), n, stride=104, read_len=100, stream=s.cuda_stream)), n, n * 108)
 ctx.scan_device_finish(s.cuda_stream)
+# segmented batch: lengths 75..301, ~17.6 K reads each, one descriptor per 64-read tile
+import numpy as np
+from sickle_amd.capi import TILE_DTYPE
+rows_per_len = 17_664  # 276 tiles
+tl = []
+at = 0
+slot = 0
+for Ls in range(75, 302):
+    st = ((Ls + 7) // 8 | 1) * 8
+    for a0 in range(0, rows_per_len, 64):
+        tl.append((at + a0 * st, slot + a0, st, 64, Ls, 0))
+    at += rows_per_len * st
+    slot += rows_per_len
+tiles_np = np.array(tl, dtype=TILE_DTYPE)
+nseg = slot
+qseg = torch.randint(40, 74, (at,), dtype=torch.uint8, device=dev)
+tiles_t = torch.from_numpy(tiles_np.view(np.uint8)).to(dev)
+oi = torch.arange(nseg, dtype=torch.int32, device=dev)
+outs = torch.empty((nseg, 2), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+import ctypes as C
+def seg():
+    b = capi.Batch(qseg.data_ptr(), None, None, 304, 0, None, nseg, tiles_t.data_ptr(), len(tiles_np), oi.data_ptr())
+    rc = capi.lib().sk_scan_device_async(ctx._h, C.byref(p), C.byref(b), outs.data_ptr(), s.cuda_stream)
+    assert rc == 0, rc
+totL = sum(rows_per_len * Ls for Ls in range(75, 302))
+report("segmented, lengths 75-301 (per-tile stride)", timeit(seg), nseg, totL + 8 * nseg)
+ctx.scan_device_finish(s.cuda_stream)
