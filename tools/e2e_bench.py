@@ -58,9 +58,13 @@ def run(binary, d, tag, p1, p2, threads):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    res = {"pairs": n, "reads": 2 * n}
+    gz = len(sys.argv) > 2 and sys.argv[2] == "gz"
+    res = {"pairs": n, "reads": 2 * n, "gzip_input": gz}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         p1, p2 = write_pair(d, n)
+        if gz:  # both tools inflate with zlib, one stream per file
+            subprocess.run(["gzip", "-1", p1, p2], check=True)
+            p1, p2 = p1 + ".gz", p2 + ".gz"
         res["input_bytes"] = os.path.getsize(p1) + os.path.getsize(p2)
         run(NEW, d, "warm", p1, p2, 1)  # first touch of the GPU runtime and the page cache
         t_new, m_new = run(NEW, d, "new", p1, p2, 1)
