@@ -469,18 +469,44 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 sk_v4i f = {(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
                 return f;
             };
-            sk_v4i q0 = load_frag(frag0), q1 = load_frag(frag1);
-            sk_v4i q0n = {0, 0, 0, 0}, q1n = {0, 0, 0, 0};
-            if (three_blocks) {
-                q0n = load_frag(frag0 + 32);
-                q1n = load_frag(frag1 + 32);
-            }
-            for (int base = 0; base < nwinmax; base += 32) {
-                sk_v16i d0, d1;
-                if (three_blocks) { // positions base .. base+95: w in 34..65
+            // 16 sign bits per accumulator block, window order; lanes 0..31 keep reads 0..31 (group
+            // 0), lanes 32..63 reads 32..63 (group 1): after the swap s[0] = windows 0..15 of the
+            // lane's own read, s[1] = windows 16..31
+            auto collect = [&](const sk_v16i &d0, const sk_v16i &d1, int base) {
+                uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p1 = __builtin_amdgcn_alignbit(p1, (uint32_t)d1[i], 31);
+                const sk_v2u s = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
+                step32((s[0] << 16) | s[1], base);
+            };
+            if (!three_blocks) { // w <= 33: positions base .. base+63, two trips per turn so that
+                                 // the fragment registers alternate instead of being copied
+                sk_v4i qa0 = load_frag(frag0), qa1 = load_frag(frag1);
+                for (int base = 0; base < nwinmax; base += 64) {
+                    const sk_v4i qb0 = load_frag(frag0 + base + 32), qb1 = load_frag(frag1 + base + 32);
+                    sk_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, qa0, negT, 0, 0, 0);
+                    sk_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, qa1, negT, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, qb0, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, qb1, d1, 0, 0, 0);
+                    collect(d0, d1, base);
+                    if (base + 32 >= nwinmax) break;
+                    qa0 = load_frag(frag0 + base + 64);
+                    qa1 = load_frag(frag1 + base + 64);
+                    sk_v16i e0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, qb0, negT, 0, 0, 0);
+                    sk_v16i e1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, qb1, negT, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, qa0, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, qa1, e1, 0, 0, 0);
+                    collect(e0, e1, base + 32);
+                }
+            } else { // w in 34..65: positions base .. base+95
+                sk_v4i q0 = load_frag(frag0), q1 = load_frag(frag1);
+                sk_v4i q0n = load_frag(frag0 + 32), q1n = load_frag(frag1 + 32);
+                for (int base = 0; base < nwinmax; base += 32) {
                     const sk_v4i q0f = load_frag(frag0 + base + 64), q1f = load_frag(frag1 + base + 64);
-                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
+                    sk_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
+                    sk_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
                     d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0n, d0, 0, 0, 0);
                     d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1n, d1, 0, 0, 0);
                     d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA2, q0f, d0, 0, 0, 0);
@@ -489,24 +515,8 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                     q1 = q1n;
                     q0n = q0f;
                     q1n = q1f;
-                } else { // positions base .. base+63: w <= 33
-                    const sk_v4i q0f = load_frag(frag0 + base + 32), q1f = load_frag(frag1 + base + 32);
-                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q0, negT, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, q1, negT, 0, 0, 0);
-                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q0f, d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, q1f, d1, 0, 0, 0);
-                    q0 = q0f;
-                    q1 = q1f;
+                    collect(d0, d1, base);
                 }
-                uint32_t p0 = 0, p1 = 0; // 16 sign bits each, window order
-#pragma unroll
-                for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) p1 = __builtin_amdgcn_alignbit(p1, (uint32_t)d1[i], 31);
-                // lanes 0..31 keep reads 0..31 (group 0), lanes 32..63 reads 32..63 (group 1):
-                // s[0] = windows 0..15 of the lane's read, s[1] = windows 16..31
-                const sk_v2u s = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
-                step32((s[0] << 16) | s[1], base);
             }
         } else {
             // ---- S_0 - T : trim.cpp:31-33
