@@ -80,6 +80,8 @@ def main():
                 # (src/trim_paired.cpp:445-458), so on many-batch inputs its batch ORDER can differ
                 # from run to run: compare the records themselves, order-independently
                 fp = os.path.join(ROOT, "tools", "probes", "fq_fingerprint.bin")
+                if not os.path.exists(fp):
+                    subprocess.run(["g++", "-O2", "-o", fp, fp[:-4] + ".cpp"], check=True)
                 same = []
                 for k in ("o1", "o2", "os"):
                     a = subprocess.run([fp, os.path.join(d, "new_%s.fastq" % k)], capture_output=True).stdout
