@@ -15,6 +15,7 @@
 
 namespace {
 constexpr size_t kBlock = 32u << 20; // bytes per read
+constexpr size_t kBgzfLargest = 0x10000; // no BGZF block is longer
 }
 
 GZReader::GZReader(const char *path_, int batch_len_, bool interleaved) : path(path_), batch_len(batch_len_)
@@ -28,15 +29,20 @@ GZReader::GZReader(const char *path_, int batch_len_, bool interleaved) : path(p
     }
     unsigned char magic[2] = {0, 0};
     const ssize_t got = pread(fd, magic, 2, 0);
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { // gzip: hand the descriptor to zlib
-        file = gzdopen(fd, "r");
-        fd = -1;
-        if (!file) {
-            fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path);
-            eof = true;
-            return;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        // gzip.  A BGZF file (first member carries a "BC" size field) is inflated block-parallel;
+        // anything else -- and whatever follows the first block that is not BGZF or does not
+        // check out -- goes through zlib's own gz reader, like the reference's gzgets.
+        struct stat st;
+        unsigned char head[18];
+        const char *off = getenv("SICKLE_NO_BGZF"); // diagnostics: force the streaming reader
+        if (!(off && *off && *off != '0') && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, head, 18, 0) == 18 && head[2] == 8 &&
+            head[3] == 4 && head[10] == 6 && head[11] == 0 && head[12] == 'B' && head[13] == 'C') {
+            bgzf = true;
+            file_size = (uint64_t)st.st_size;
+        } else {
+            stream_from(0);
         }
-        gzbuffer(file, 4u << 20);
     } else {
         posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
         struct stat st;
@@ -53,16 +59,182 @@ GZReader::~GZReader()
     if (fd >= 0) close(fd);
 }
 
+void GZReader::stream_from(uint64_t offset)
+{
+    bgzf = false;
+    lseek(fd, (off_t)offset, SEEK_SET);
+    file = gzdopen(fd, "r");
+    fd = -1;
+    if (!file) {
+        fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path);
+        eof = in_eof = true;
+        return;
+    }
+    gzbuffer(file, 4u << 20);
+}
+
+namespace {
+struct Inflater { // one raw-inflate state per worker thread, reset per block
+    z_stream zs;
+    bool live = false;
+    ~Inflater()
+    {
+        if (live) inflateEnd(&zs);
+    }
+    bool prepare()
+    {
+        if (live) return inflateReset(&zs) == Z_OK;
+        memset(&zs, 0, sizeof zs);
+        live = inflateInit2(&zs, -15) == Z_OK;
+        return live;
+    }
+};
+} // namespace
+
+// Loads the next chunk of compressed bytes, walks the block headers (each says how long its block
+// is: SAM spec 4.1), and inflates the blocks side by side into pending[old...).  Returns the bytes
+// produced.  A header that is not BGZF, a block cut off by the end of the file, or a block whose
+// data, length or CRC does not check out ends the parallel part: everything before it is kept and
+// the rest of the file is read by zlib's gzread, which then behaves (and fails) like the
+// reference's reader on the same bytes.
+size_t GZReader::fill_bgzf(size_t old)
+{
+    constexpr uint64_t kChunk = 24u << 20;
+    const uint64_t want = std::min<uint64_t>(kChunk, file_size - file_pos);
+    if (want == 0) {
+        in_eof = true;
+        return 0;
+    }
+    cbuf.reserve((size_t)want);
+    unsigned char *c = (unsigned char *)cbuf.data();
+    {
+        const uint64_t base = file_pos;
+        std::atomic<bool> failed{false};
+        const size_t slices = (size_t)std::min<uint64_t>(8, (want + (4u << 20) - 1) / (4u << 20));
+        WorkerPool::instance().parallel_for((size_t)want, slices, [&](size_t b, size_t e, size_t) {
+            size_t done = b;
+            while (done < e) {
+                const ssize_t r = pread(fd, c + done, e - done, (off_t)(base + done));
+                if (r <= 0) {
+                    failed = true;
+                    return;
+                }
+                done += (size_t)r;
+            }
+        });
+        if (failed) {
+            fprintf(stderr, "****Error: could not read input file '%s'.\n\n", path);
+            exit(EXIT_FAILURE);
+        }
+    }
+    struct Blk {
+        size_t at, data, clen, out;
+        uint32_t isize, crc;
+    };
+    std::vector<Blk> blks;
+    size_t at = 0, out = 0;
+    bool foreign = false; // stopped at something that is not a whole BGZF block
+    while (at < want && out < kBlock) {
+        const unsigned char *h = c + at;
+        if (at + 18 > want) {
+            foreign = true;
+            break;
+        }
+        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || at + 12 + xlen > want) {
+            foreign = true;
+            break;
+        }
+        size_t total = 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const unsigned char *f = h + 12 + x;
+            const size_t flen = (size_t)f[2] | ((size_t)f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && flen == 2 && x + 6 <= xlen) total = ((size_t)f[4] | ((size_t)f[5] << 8)) + 1;
+            x += 4 + flen;
+        }
+        if (total < 12 + xlen + 8 || at + total > want) {
+            foreign = true;
+            break;
+        }
+        const unsigned char *t = h + total - 8;
+        const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (isize > 0x10000) {
+            foreign = true;
+            break;
+        }
+        blks.push_back({at, at + 12 + xlen, total - 12 - xlen - 8, out, isize, crc});
+        out += isize;
+        at += total;
+    }
+    // a chunk boundary in the middle of a block is not foreign: the next call starts at that block
+    if (foreign && blks.empty() == false && at + kBgzfLargest > want && file_pos + want < file_size) foreign = false;
+    pending.reserve(old + out);
+    char *dst = pending.data() + old;
+    std::atomic<size_t> bad{blks.size()};
+    WorkerPool &pool = WorkerPool::instance();
+    pool.parallel_for(blks.size(), std::min(blks.size(), (size_t)pool.size() * 4), [&](size_t lo, size_t hi, size_t) {
+        static thread_local Inflater inf;
+        for (size_t i = lo; i < hi; ++i) {
+            const Blk &b = blks[i];
+            bool ok = b.isize == 0 ? b.crc == 0 : inf.prepare(); // the empty end-of-file block
+            if (ok && b.isize) {
+                inf.zs.next_in = c + b.data;
+                inf.zs.avail_in = (uInt)b.clen;
+                inf.zs.next_out = (Bytef *)dst + b.out;
+                inf.zs.avail_out = b.isize;
+                ok = inflate(&inf.zs, Z_FINISH) == Z_STREAM_END && inf.zs.total_out == b.isize && inf.zs.avail_in == 0 &&
+                     (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)dst + b.out, b.isize) == b.crc;
+            }
+            if (!ok) {
+                size_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+                }
+                return;
+            }
+        }
+    });
+    const size_t nbad = bad.load();
+    if (nbad < blks.size()) {
+        stream_from(file_pos + blks[nbad].at);
+        return blks[nbad].out;
+    }
+    if (foreign) {
+        stream_from(file_pos + at);
+        return out;
+    }
+    file_pos += at;
+    if (file_pos >= file_size) in_eof = true;
+    return out;
+}
+
 bool GZReader::fill()
 {
     if (in_eof) return false;
     const size_t old = pending.size();
-    pending.reserve(old + kBlock);
     size_t got = 0;
+    while (bgzf && got == 0 && !in_eof) got = fill_bgzf(old);
+    if (got > 0 || in_eof) {
+        pending.set_size(old + got);
+        return got > 0;
+    }
+    pending.reserve(old + kBlock);
     if (file) {
-        const int r = gzread(file, pending.data() + old, (unsigned)kBlock);
-        got = r > 0 ? (size_t)r : 0;
-        if (got < kBlock) in_eof = true;
+        // in pieces: a gzread call that runs into damaged data returns nothing at all, and what
+        // the earlier pieces delivered is kept (the reference's gzgets keeps the lines before it)
+        constexpr unsigned kPiece = 1u << 20;
+        while (got < kBlock) {
+            const int r = gzread(file, pending.data() + old + got, kPiece);
+            if (r > 0) got += (size_t)r;
+            if (r < (int)kPiece) {
+                in_eof = true;
+                int zerr = Z_OK;
+                const char *what = gzerror(file, &zerr);
+                if (r < 0 || (zerr != Z_OK && zerr != Z_STREAM_END))
+                    fprintf(stderr, "****Warning: '%s': %s; the input ends there.\n", path, what);
+                break;
+            }
+        }
     } else if (regular) {
         // one block = several slices pread concurrently on the host pool (a single read(2) stream
         // is a page-cache memcpy on one core, ~3 GB/s; slices scale with the cores)

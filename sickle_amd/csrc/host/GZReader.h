@@ -2,7 +2,9 @@
 //
 // Role of reference src/GZReader.{h,cpp} and src/Batch.{h,cpp}; written fresh.  The reference
 // reads line by line with gzgets into one heap string per line; this reader pulls large blocks
-// (read(2) for plain files, gzread for gzip) straight into the batch's own text buffer, finds
+// (read(2) for plain files, gzread for gzip, and for BGZF -- blocked gzip as written by bgzip and
+// by this program's own -g -- all blocks of a chunk inflated at once on the host threads)
+// straight into the batch's own text buffer, finds
 // the newlines of a block with all host threads at once, and indexes the lines in place.  What
 // it keeps is the reference's BATCH CUT RULE, because that rule is observable:
 //   - a batch ends after the line that drives the byte budget to <= 0 (src/GZReader.cpp:61-92),
@@ -96,11 +98,15 @@ public:
 
 private:
     bool fill();        // read another block behind `pending`
+    size_t fill_bgzf(size_t old); // BGZF input: inflate the next run of blocks behind pending[old)
+    void stream_from(uint64_t offset); // give the rest of a gzip file to zlib's own reader
     void index_more();  // find the newlines of the bytes not yet indexed
 
     gzFile file = nullptr; // gzip input
     int fd = -1;           // plain input: read(2) / parallel pread(2), no zlib copy
     bool regular = false;  // a regular file of known size: blocks are pread in parallel slices
+    bool bgzf = false;     // gzip input whose members carry their size (BGZF): inflated in parallel
+    RawBuf cbuf;           // compressed bytes of the current BGZF chunk
     uint64_t file_size = 0, file_pos = 0;
     bool eof = false;      // gzgets would have returned NULL: no further batch
     bool in_eof = false;   // the underlying stream is exhausted

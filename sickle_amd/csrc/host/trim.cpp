@@ -28,15 +28,12 @@ void msg(const char *content)
 void msg(const std::string &content) { msg(content.c_str()); }
 
 // ---------------------------------------------------------------- OutFile
-bool OutFile::open(const char *path, bool gzip)
+bool OutFile::open(const char *path, bool gz)
 {
-    if (gzip) {
-        gz = gzopen(path, "w");
-        if (gz) gzbuffer(gz, 1u << 20);
-        return gz != nullptr;
-    }
     fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     pos = 0;
+    gzip = gz;
+    if (const char *e = getenv("SICKLE_GZ_LEVEL")) gz_level = std::max(1, std::min(9, atoi(e)));
     struct stat st;
     seekable = fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
     return fd >= 0;
@@ -63,28 +60,120 @@ static void pwrite_all(int fd, const char *p, size_t n, uint64_t at)
     }
 }
 
-void OutFile::write(const std::string &data)
+void OutFile::put(const char *p, size_t n)
 {
-    if (data.empty()) return;
-    if (fd >= 0) {
-        if (seekable) pwrite_all(fd, data.data(), data.size(), pos);
-        else write_all(fd, data.data(), data.size());
-        pos += data.size();
-    } else if (gz) {
-        // The reference hands the text to gzprintf as the FORMAT string (src/trim_single.cpp:418),
-        // which mangles any '%' (= Sanger Q4).  This writes the bytes themselves.
-        size_t done = 0;
-        while (done < data.size()) {
-            const unsigned n = (unsigned)std::min<size_t>(data.size() - done, 1u << 30);
-            if (gzwrite(gz, data.data() + done, n) <= 0) break;
-            done += n;
+    if (seekable) pwrite_all(fd, p, n, pos);
+    else write_all(fd, p, n);
+    pos += n;
+}
+
+// ---- gzip output as BGZF (the blocked gzip of htslib's bgzip: SAM/BAM spec §4.1).  Every block
+// is a complete gzip member of at most 64 KiB whose header carries its own compressed size in a
+// "BC" extra field, so any gzip reader inflates the file as one stream (RFC 1952 §2.2) and a
+// BGZF-aware one -- GZReader here, bgzip -@, samtools -- finds the block boundaries without
+// inflating and works on the blocks in parallel.
+namespace {
+constexpr size_t kBgzfInput = 0xff00; // payload bytes per block, as bgzip
+constexpr size_t kBgzfMaxBlock = 0x10000;
+const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct Deflater { // one raw-deflate state per worker thread and level, reset per block
+    z_stream zs;
+    int level = -100;
+    bool live = false;
+    ~Deflater()
+    {
+        if (live) deflateEnd(&zs);
+    }
+    void prepare(int lvl)
+    {
+        if (live && lvl == level) {
+            deflateReset(&zs);
+            return;
+        }
+        if (live) deflateEnd(&zs);
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, lvl, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            error("deflateInit2 failed");
+            exit(EXIT_FAILURE);
+        }
+        live = true;
+        level = lvl;
+    }
+};
+
+// appends the block holding [p, p+n), n <= kBgzfInput, to out
+void bgzf_block(const char *p, size_t n, int level, std::string &out)
+{
+    static thread_local Deflater d;
+    const size_t at = out.size();
+    out.resize(at + kBgzfMaxBlock);
+    unsigned char *blk = (unsigned char *)out.data() + at;
+    memcpy(blk, kBgzfEof, 16);
+    size_t clen = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        d.prepare(attempt == 0 ? level : 0); // incompressible data: stored blocks always fit
+        d.zs.next_in = (Bytef *)p;
+        d.zs.avail_in = (uInt)n;
+        d.zs.next_out = blk + 18;
+        d.zs.avail_out = (uInt)(kBgzfMaxBlock - 18 - 8);
+        if (deflate(&d.zs, Z_FINISH) == Z_STREAM_END) {
+            clen = d.zs.total_out;
+            break;
+        }
+        if (attempt == 1) {
+            error("deflate failed");
+            exit(EXIT_FAILURE);
         }
     }
+    const uint32_t total = (uint32_t)(18 + clen + 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)p, (uInt)n);
+    blk[16] = (unsigned char)((total - 1) & 0xff);
+    blk[17] = (unsigned char)((total - 1) >> 8);
+    unsigned char *tail = blk + 18 + clen;
+    for (int i = 0; i < 4; ++i) tail[i] = (unsigned char)(crc >> (8 * i));
+    for (int i = 0; i < 4; ++i) tail[4 + i] = (unsigned char)((uint32_t)n >> (8 * i));
+    out.resize(at + total);
+}
+} // namespace
+
+void OutFile::write(const std::string &data)
+{
+    if (data.empty() || fd < 0) return;
+    if (!gzip) {
+        put(data.data(), data.size());
+        return;
+    }
+    // The reference hands the text to gzprintf as the FORMAT string (src/trim_single.cpp:418),
+    // which mangles any '%' (= Sanger Q4).  This writes the bytes themselves.
+    std::vector<std::string> one;
+    one.push_back(data);
+    write_parts(one);
 }
 
 void OutFile::write_parts(const std::vector<std::string> &parts)
 {
-    if (fd < 0 || !seekable) {
+    if (fd < 0) return;
+    if (gzip) {
+        struct Piece {
+            const char *p;
+            size_t n;
+        };
+        std::vector<Piece> pieces;
+        for (const std::string &s : parts)
+            for (size_t at = 0; at < s.size(); at += kBgzfInput)
+                pieces.push_back({s.data() + at, std::min(kBgzfInput, s.size() - at)});
+        if (pieces.empty()) return;
+        const size_t groups = std::min(pieces.size(), (size_t)WorkerPool::instance().size() * 4);
+        std::vector<std::string> packed(groups);
+        WorkerPool::instance().parallel_for(pieces.size(), groups, [&](size_t lo, size_t hi, size_t g) {
+            packed[g].reserve((hi - lo) * (kBgzfInput / 3));
+            for (size_t i = lo; i < hi; ++i) bgzf_block(pieces[i].p, pieces[i].n, gz_level, packed[g]);
+        });
+        for (const std::string &m : packed) put(m.data(), m.size());
+        return;
+    }
+    if (!seekable) {
         for (const std::string &p : parts) write(p);
         return;
     }
@@ -98,10 +187,11 @@ void OutFile::write_parts(const std::vector<std::string> &parts)
 
 void OutFile::close()
 {
-    if (fd >= 0) ::close(fd);
-    if (gz) gzclose(gz);
+    if (fd >= 0) {
+        if (gzip) put((const char *)kBgzfEof, sizeof kBgzfEof); // the empty block that ends a BGZF file
+        ::close(fd);
+    }
     fd = -1;
-    gz = nullptr;
 }
 
 // ---------------------------------------------------------------- Abstract_Trimmer

@@ -33,16 +33,19 @@ public:
     bool open(const char *path, bool gzip);
     void write(const std::string &data);
     // the pieces of one batch, in order: plain files take them as concurrent pwrite(2) slices
-    // (a single write stream is a page-cache memcpy on one core), gzip files one after the other
+    // (a single write stream is a page-cache memcpy on one core); gzip files are deflated on the
+    // worker pool as BGZF blocks (gzip members of <= 64 KiB) and the blocks written in order
     void write_parts(const std::vector<std::string> &parts);
     void close();
-    bool is_open() const { return fd >= 0 || gz; }
+    bool is_open() const { return fd >= 0; }
 
 private:
+    void put(const char *p, size_t n); // at the current position
     int fd = -1;
     bool seekable = false; // a regular file: positional writes; pipes and devices get plain write(2)
+    bool gzip = false;
+    int gz_level = -1; // zlib's default, what the reference's gzopen(path, "w") uses
     uint64_t pos = 0;
-    gzFile gz = nullptr;
 };
 
 // Wall-clock accumulators per pipeline stage, printed to stderr when SICKLE_STAGE_TIMES=1.

@@ -46,22 +46,65 @@ def write_pair(d, n, chunk=250_000):
     return p1, p2
 
 
-def run(binary, d, tag, p1, p2, threads):
+def run(binary, d, tag, p1, p2, threads, gzout=False):
     outs = [os.path.join(d, "%s_%s.fastq" % (tag, k)) for k in ("o1", "o2", "os")]
     t0 = time.perf_counter()
     pr = subprocess.run([binary, "pe", "-f", p1, "-r", p2, "-t", "sanger", "-o", outs[0], "-p", outs[1], "-s", outs[2],
-                         "-a", str(threads)], capture_output=True)
+                         "-a", str(threads)] + (["-g"] if gzout else []), capture_output=True)
     dt = time.perf_counter() - t0
     assert pr.returncode == 0, pr.stderr.decode()[-500:]
+    if gzout:  # compare what the files inflate to (any gzip reader: here zcat)
+        sums = []
+        for o in outs:
+            h = hashlib.md5()
+            z = subprocess.Popen(["zcat", o], stdout=subprocess.PIPE)
+            for blk in iter(lambda: z.stdout.read(1 << 24), b""):
+                h.update(blk)
+            assert z.wait() == 0
+            sums.append(h.hexdigest())
+        return dt, sums, sum(os.path.getsize(o) for o in outs)
     return dt, [md5(o) for o in outs]
+
+
+def to_bgzf(d, path):
+    """A BGZF copy of a FASTQ file, made by this CLI itself: -q 0 -l 0 keeps every read whole."""
+    out = path + ".bgzf.gz"
+    pr = subprocess.run([NEW, "se", "-f", path, "-t", "sanger", "-o", out, "-q", "0", "-l", "0", "-g"], capture_output=True)
+    assert pr.returncode == 0, pr.stderr.decode()[-500:]
+    return out
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    gz = len(sys.argv) > 2 and sys.argv[2] == "gz"
-    res = {"pairs": n, "reads": 2 * n, "gzip_input": gz}
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    gz = mode == "gz"
+    res = {"pairs": n, "reads": 2 * n, "gzip_input": gz, "mode": mode}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         p1, p2 = write_pair(d, n)
+        if mode in ("bgzf", "gzout"):
+            # BGZF input and/or -g output of this CLI against its own plain run (the reference's -g
+            # hands the records to gzprintf as a format string and cannot be compared)
+            run(NEW, d, "warm", p1, p2, 1)
+            t_plain, m_plain = run(NEW, d, "plain", p1, p2, 1)
+            res["plain_s"] = t_plain
+            if mode == "bgzf":
+                b1, b2 = to_bgzf(d, p1), to_bgzf(d, p2)
+                assert subprocess.run("zcat %s | cmp - %s" % (b1, p1), shell=True).returncode == 0
+                res["bgzf_input_bytes"] = os.path.getsize(b1) + os.path.getsize(b2)
+                t, m = run(NEW, d, "bgzf", b1, b2, 1)
+                res["bgzf_in_s"], res["bgzf_in_reads_per_s"], res["bgzf_in_identical"] = t, 2 * n / t, m == m_plain
+                env = dict(os.environ, SICKLE_NO_BGZF="1")
+                t0 = time.perf_counter()
+                pr = subprocess.run([NEW, "pe", "-f", b1, "-r", b2, "-t", "sanger", "-o", d + "/s1", "-p", d + "/s2", "-s",
+                                     d + "/s3"], capture_output=True, env=env)
+                res["same_file_streamed_s"] = time.perf_counter() - t0
+                assert pr.returncode == 0
+            else:
+                t, m, size = run(NEW, d, "gzout", p1, p2, 1, gzout=True)
+                res["gz_out_s"], res["gz_out_reads_per_s"], res["gz_out_identical"] = t, 2 * n / t, m == m_plain
+                res["gz_out_bytes"] = size
+            print(json.dumps(res))
+            return
         if gz:  # both tools inflate with zlib, one stream per file
             subprocess.run(["gzip", "-1", p1, p2], check=True)
             p1, p2 = p1 + ".gz", p2 + ".gz"
