@@ -1,6 +1,7 @@
 #include "GZReader.h"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -55,6 +56,8 @@ GZReader::GZReader(const char *path_, int batch_len_, bool interleaved) : path(p
 
 GZReader::~GZReader()
 {
+    delete fast;
+    if (map) munmap((void *)map, map_len);
     if (file) gzclose(file);
     if (fd >= 0) close(fd);
 }
@@ -62,6 +65,18 @@ GZReader::~GZReader()
 void GZReader::stream_from(uint64_t offset)
 {
     bgzf = false;
+    struct stat st;
+    const char *z = getenv("SICKLE_ZLIB_INFLATE"); // diagnostics: decode with zlib instead
+    if (!(z && *z && *z != '0') && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (uint64_t)st.st_size > offset) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            map = (const unsigned char *)m;
+            map_len = (size_t)st.st_size;
+            fast = new GzInflater(map + offset, map_len - (size_t)offset);
+            return;
+        }
+    }
     lseek(fd, (off_t)offset, SEEK_SET);
     file = gzdopen(fd, "r");
     fd = -1;
@@ -219,7 +234,11 @@ bool GZReader::fill()
         return got > 0;
     }
     pending.reserve(old + kBlock);
-    if (file) {
+    if (fast) {
+        got = fast->read(pending.data() + old, kBlock);
+        if (fast->finished()) in_eof = true;
+        if (fast->error()) fprintf(stderr, "****Warning: '%s': %s; the input ends there.\n", path, fast->error());
+    } else if (file) {
         // in pieces: a gzread call that runs into damaged data returns nothing at all, and what
         // the earlier pieces delivered is kept (the reference's gzgets keeps the lines before it)
         constexpr unsigned kPiece = 1u << 20;

@@ -2,8 +2,9 @@
 //
 // Role of reference src/GZReader.{h,cpp} and src/Batch.{h,cpp}; written fresh.  The reference
 // reads line by line with gzgets into one heap string per line; this reader pulls large blocks
-// (read(2) for plain files, gzread for gzip, and for BGZF -- blocked gzip as written by bgzip and
-// by this program's own -g -- all blocks of a chunk inflated at once on the host threads)
+// (read(2) for plain files; gzip through GzInflater on the mapped file, or zlib's gzread when the
+// input is not a regular file; and for BGZF -- blocked gzip as written by bgzip and by this
+// program's own -g -- all blocks of a chunk inflated at once on the host threads)
 // straight into the batch's own text buffer, finds
 // the newlines of a block with all host threads at once, and indexes the lines in place.  What
 // it keeps is the reference's BATCH CUT RULE, because that rule is observable:
@@ -22,6 +23,8 @@
 #define SICKLE_GZREADER_H
 
 #include <zlib.h>
+
+#include "GzInflater.h"
 
 #include <cstdint>
 #include <cstdlib>
@@ -99,10 +102,13 @@ public:
 private:
     bool fill();        // read another block behind `pending`
     size_t fill_bgzf(size_t old); // BGZF input: inflate the next run of blocks behind pending[old)
-    void stream_from(uint64_t offset); // give the rest of a gzip file to zlib's own reader
+    void stream_from(uint64_t offset); // the rest of a gzip file as one serial stream
     void index_more();  // find the newlines of the bytes not yet indexed
 
-    gzFile file = nullptr; // gzip input
+    gzFile file = nullptr; // gzip input read through zlib (pipes, SICKLE_ZLIB_INFLATE=1)
+    GzInflater *fast = nullptr; // gzip input decoded from the mapped file
+    const unsigned char *map = nullptr;
+    size_t map_len = 0;
     int fd = -1;           // plain input: read(2) / parallel pread(2), no zlib copy
     bool regular = false;  // a regular file of known size: blocks are pread in parallel slices
     bool bgzf = false;     // gzip input whose members carry their size (BGZF): inflated in parallel

@@ -1,0 +1,98 @@
+"""GzInflater (sickle_amd/csrc/host/GzInflater.cpp), the gzip decoder of the ingest, against zlib
+on the same bytes: every compression level and strategy, stored / fixed / dynamic blocks, long
+Huffman codes (subtables), matches at the far end of the window, concatenated members with trailing
+garbage, all optional header fields, odd read sizes, and randomly damaged or truncated files (no
+crash, never silently wrong bytes).  CPU only; tests/cpu_shim/inflate_check is test infrastructure."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import cli_util as cu
+
+BIN = os.path.join(cu.ROOT, "tests", "cpu_shim", "inflate_check")
+TEXT = open(os.path.join(cu.INPUTS, "test.fastq"), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def inflate_check():
+    subprocess.run(["make", "-s", "-C", os.path.join(cu.ROOT, "tests", "cpu_shim"), "all"], check=True)
+    return BIN
+
+
+def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8, wbits=31):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def with_all_header_fields(data):
+    body = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = body.compress(data) + body.flush()
+    h = b"\x1f\x8b\x08" + bytes([4 | 8 | 16 | 2]) + b"\0\0\0\0\0\x03" + struct.pack("<H", 5) + b"ab\x01\x00z" + b"name.fq\0" + b"a comment\0"
+    h += struct.pack("<H", zlib.crc32(h) & 0xffff)
+    return h + raw + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data) & 0xffffffff)
+
+
+def cases():
+    rng = np.random.default_rng(5)
+    rnd = rng.integers(0, 256, 1_000_000, dtype=np.uint8).tobytes()
+    skew = rng.choice(np.arange(256, dtype=np.uint8), 1_000_000, p=np.r_[[0.5, 0.2, 0.1], np.full(253, 0.2 / 253)]).tobytes()
+    zipf = (rng.zipf(1.3, 1_000_000) % 256).astype(np.uint8).tobytes()
+    far = rng.integers(0, 256, 32700, dtype=np.uint8).tobytes()
+    out = {"empty": (gz(b""), b""), "one": (gz(b"A"), b"A")}
+    for lv in range(10):
+        out["level%d" % lv] = (gz(TEXT, lv), TEXT)
+    for name, st in (("fixed", zlib.Z_FIXED), ("huffman_only", zlib.Z_HUFFMAN_ONLY), ("rle", zlib.Z_RLE), ("filtered", zlib.Z_FILTERED)):
+        out[name] = (gz(TEXT, 6, st), TEXT)
+    out["memlevel1"] = (gz(TEXT * 2, 9, memlevel=1), TEXT * 2)
+    out["window512"] = (gz(TEXT, 9, wbits=16 + 9), TEXT)
+    out["random"] = (gz(rnd), rnd)
+    out["random_stored"] = (gz(rnd, 0), rnd)
+    runs = b"A" * 1_000_000 + b"BC" * 500_000 + b"xyz" * 300_000 + b"\0" * 70000
+    out["runs"] = (gz(runs), runs)
+    out["long_codes"] = (gz(skew, 9), skew)
+    out["zipf"] = (gz(zipf, 9), zipf)
+    out["far_matches"] = (gz(far * 30, 9), far * 30)
+    out["members"] = (gz(TEXT) + gz(b"") + gz(rnd[:100000], 0) + gz(TEXT[:12345], 9) + b"\0\0\0trailing garbage",
+                      TEXT + rnd[:100000] + TEXT[:12345])
+    out["header_fields"] = (with_all_header_fields(TEXT[:50000]) + gz(TEXT[50000:90000]), TEXT[:90000])
+    out["many_chunks"] = (gz(TEXT * 12), TEXT * 12)
+    return out
+
+
+def test_decodes_like_zlib(inflate_check, tmp_path):
+    for name, (blob, want) in cases().items():
+        assert name == "members" or gzip.decompress(blob) == want  # (python's gzip rejects trailing garbage; zlib's gzread and the reference do not)
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(blob)
+        for piece in (32 << 20, 1, 7, 4096, 65537, 300000):
+            if piece < 100 and len(want) > 200000:
+                continue
+            pr = subprocess.run([inflate_check, path, str(piece)], capture_output=True)
+            assert pr.returncode == 0 and pr.stdout == want, (name, piece, pr.stderr[:200])
+
+
+def test_damaged_input_is_reported(inflate_check, tmp_path):
+    rng = np.random.default_rng(9)
+    blob = gz(TEXT)
+    path = str(tmp_path / "dmg.gz")
+    silent_ok = 0
+    for k in range(150):
+        b = bytearray(blob)
+        at = int(rng.integers(10, len(b)))
+        b[at] ^= 1 << int(rng.integers(0, 8))
+        if k % 3 == 0:
+            b = b[:at]
+        open(path, "wb").write(bytes(b))
+        pr = subprocess.run([inflate_check, path], capture_output=True)
+        assert pr.returncode in (0, 2), (k, at, pr.returncode)  # 2 = error reported; anything else is a crash
+        if pr.returncode == 0:
+            assert pr.stdout == TEXT, (k, at)  # e.g. a flipped bit in the ISIZE-irrelevant header bytes
+            silent_ok += 1
+        else:
+            assert b"error:" in pr.stderr
+    assert silent_ok < 10

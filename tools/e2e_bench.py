@@ -69,7 +69,7 @@ def run(binary, d, tag, p1, p2, threads, gzout=False):
 def to_bgzf(d, path):
     """A BGZF copy of a FASTQ file, made by this CLI itself: -q 0 -l 0 keeps every read whole."""
     out = path + ".bgzf.gz"
-    pr = subprocess.run([NEW, "se", "-f", path, "-t", "sanger", "-o", out, "-q", "0", "-l", "0", "-g"], capture_output=True)
+    pr = subprocess.run([NEW, "se", "-f", path, "-t", "sanger", "-o", out, "-q", "0", "-l", "0", "-g", "-a", "1"], capture_output=True)
     assert pr.returncode == 0, pr.stderr.decode()[-500:]
     return out
 
