@@ -15,13 +15,14 @@
 #include <cstdint>
 #include <vector>
 
-class GzInflater {
+#include "Deflate.h"
+
+class GzInflater : public DeflateStream {
 public:
     GzInflater(const unsigned char *data, size_t size);
     // up to `want` decoded bytes into dst; fewer only at the end of the input or on an error
     size_t read(char *dst, size_t want);
     bool finished() const { return state == DONE || state == FAILED; }
-    const char *error() const { return err; }
 
 private:
     enum State { MEMBER_HEADER, BLOCK_HEADER, STORED, HUFFMAN, MEMBER_TRAILER, DONE, FAILED };
@@ -29,32 +30,18 @@ private:
         uint64_t abs_off; // decoded bytes of the whole input up to the end of this member
         uint32_t crc, isize;
     };
-    static constexpr int kLitBits = 11, kDistBits = 8;
     static constexpr size_t kWindow = 32768, kChunk = 256 * 1024, kSlack = 512;
 
-    bool fail(const char *what);
     bool member_header();
     bool block_header();
-    bool dynamic_tables();
-    void fixed_tables();
-    bool build(const uint8_t *lens, int n, uint32_t *table, int primary_bits, bool dist);
     bool run_huffman(size_t olimit);
     template <bool FAST> bool huffman_loop(size_t olimit, bool &block_done);
     bool run_stored(size_t olimit);
     bool member_trailer();
-    bool need_bits(int n);
-    uint32_t take_bits(int n);
-    void align_to_byte();
     bool verify(const char *dst, size_t produced);
 
-    const unsigned char *in, *in_end;
-    uint64_t bitbuf = 0;
-    int bitcnt = 0;
     State state = MEMBER_HEADER;
-    const char *err = nullptr;
-    bool last_block = false;
     bool first_member = true;
-    size_t stored_left = 0;
 
     std::vector<unsigned char> win; // [history | bytes being produced | slack]
     size_t opos = 0;                // decoded up to here
@@ -67,9 +54,6 @@ private:
     uint64_t len_running = 0;
     std::vector<MemberEnd> ends; // members whose trailer has been read and whose bytes are not all checked yet
 
-    uint32_t lit_table[(1 << kLitBits) + 288 * 16];
-    uint32_t dist_table[(1 << kDistBits) + 32 * 128];
-    bool tables_are_fixed = false;
 };
 
 #endif
