@@ -1,6 +1,36 @@
 #include "Deflate.h"
 
+#include <zlib.h> // crc32, crc32_combine only
+
+#include <algorithm>
+#include <vector>
+
+#include "WorkerPool.h"
+
 using namespace deflate_detail;
+
+// CRC-32 of a large buffer on all host threads (slices combined with crc32_combine)
+uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n)
+{
+    if (n < (4u << 20)) return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = std::min<size_t>((size_t)pool.size() * 2, n / (1u << 20));
+    std::vector<uint32_t> crc(parts);
+    std::vector<size_t> len(parts);
+    pool.parallel_for(n, parts, [&](size_t b, size_t e, size_t part) {
+        uLong c = crc32(0L, Z_NULL, 0);
+        for (size_t at = b; at < e;) { // crc32 takes a 32-bit length
+            const size_t m = std::min<size_t>(e - at, 1u << 30);
+            c = crc32(c, p + at, (uInt)m);
+            at += m;
+        }
+        crc[part] = (uint32_t)c;
+        len[part] = e - b;
+    });
+    uLong c = crc[0];
+    for (size_t i = 1; i < parts; ++i) c = crc32_combine(c, crc[i], (z_off_t)len[i]);
+    return (uint32_t)c;
+}
 
 // ---- careful bit reader (headers, and the decode loops near the end of the input)
 bool DeflateStream::need_bits(int n)
@@ -77,6 +107,13 @@ bool DeflateStream::build(const uint8_t *lens, int n, uint32_t *table, int prima
     for (int l = 1; l <= 15; ++l) {
         left = (left << 1) - count[l];
         if (left < 0) return fail("invalid code lengths set");
+    }
+    if (dist) {
+        dist_complete = left == 0;
+        dist_codes = 0;
+        for (int l = 1; l <= 15; ++l) dist_codes += count[l];
+    } else {
+        lit_complete = left == 0;
     }
     uint32_t next_code[16];
     uint32_t code = 0;

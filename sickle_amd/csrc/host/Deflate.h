@@ -36,6 +36,18 @@ inline void store16(unsigned char *p, uint16_t v) { memcpy(p, &v, 2); }
 
 } // namespace deflate_detail
 
+uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n);
+
+// what GZReader pulls decoded bytes from
+class GzSource {
+public:
+    virtual ~GzSource() {}
+    // up to `want` decoded bytes into dst; fewer only at the end of the input or on an error
+    virtual size_t read(char *dst, size_t want) = 0;
+    virtual bool finished() const = 0;
+    virtual const char *error() const = 0;
+};
+
 class DeflateStream {
 public:
     static constexpr int kLitBits = 11, kDistBits = 8;
@@ -68,6 +80,10 @@ protected:
     uint32_t lit_table[(1 << kLitBits) + 288 * 16];
     uint32_t dist_table[(1 << kDistBits) + 32 * 128];
     bool tables_are_fixed = false;
+    // of the tables built last: does every bit string decode (Kraft sum exactly 1)?  A compressor
+    // writes complete codes (or a single distance code); random bits almost never form them.
+    bool lit_complete = false, dist_complete = false;
+    int dist_codes = 0;
 };
 
 #endif

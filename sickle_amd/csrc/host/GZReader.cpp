@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "GzInflater.h"
+#include "GzParallel.h"
 #include "WorkerPool.h"
 #include "sickle.h"
 
@@ -73,7 +75,13 @@ void GZReader::stream_from(uint64_t offset)
             madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
             map = (const unsigned char *)m;
             map_len = (size_t)st.st_size;
-            fast = new GzInflater(map + offset, map_len - (size_t)offset);
+            // small inputs are not worth cutting up; SICKLE_GZ_SERIAL=1 keeps to the serial decoder
+            const char *ser = getenv("SICKLE_GZ_SERIAL");
+            const size_t left = map_len - (size_t)offset;
+            const char *ch = getenv("SICKLE_GZ_CHUNK"); // diagnostics/tests: compressed bytes per stretch
+            if (ch && atol(ch) > 0) fast = new GzParallel(map + offset, left, (size_t)atol(ch));
+            else if (left < (8u << 20) || (ser && *ser && *ser != '0')) fast = new GzInflater(map + offset, left);
+            else fast = new GzParallel(map + offset, left);
             return;
         }
     }

@@ -2,8 +2,8 @@
 //
 // Role of reference src/GZReader.{h,cpp} and src/Batch.{h,cpp}; written fresh.  The reference
 // reads line by line with gzgets into one heap string per line; this reader pulls large blocks
-// (read(2) for plain files; gzip through GzInflater on the mapped file, or zlib's gzread when the
-// input is not a regular file; and for BGZF -- blocked gzip as written by bgzip and by this
+// (read(2) for plain files; gzip decoded from the mapped file on all host threads (GzParallel), or
+// through zlib's gzread when the input is not a regular file; and for BGZF -- blocked gzip as written by bgzip and by this
 // program's own -g -- all blocks of a chunk inflated at once on the host threads)
 // straight into the batch's own text buffer, finds
 // the newlines of a block with all host threads at once, and indexes the lines in place.  What
@@ -24,7 +24,7 @@
 
 #include <zlib.h>
 
-#include "GzInflater.h"
+#include "Deflate.h"
 
 #include <cstdint>
 #include <cstdlib>
@@ -106,7 +106,7 @@ private:
     void index_more();  // find the newlines of the bytes not yet indexed
 
     gzFile file = nullptr; // gzip input read through zlib (pipes, SICKLE_ZLIB_INFLATE=1)
-    GzInflater *fast = nullptr; // gzip input decoded from the mapped file
+    GzSource *fast = nullptr;   // gzip input decoded from the mapped file (GzParallel, or GzInflater for small files)
     const unsigned char *map = nullptr;
     size_t map_len = 0;
     int fd = -1;           // plain input: read(2) / parallel pread(2), no zlib copy

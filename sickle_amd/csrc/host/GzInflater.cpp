@@ -9,29 +9,6 @@
 
 using namespace deflate_detail;
 
-namespace {
-uint32_t parallel_crc(const unsigned char *p, size_t n)
-{
-    if (n < (4u << 20)) return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
-    WorkerPool &pool = WorkerPool::instance();
-    const size_t parts = std::min<size_t>((size_t)pool.size() * 2, n / (1u << 20));
-    std::vector<uint32_t> crc(parts);
-    std::vector<size_t> len(parts);
-    pool.parallel_for(n, parts, [&](size_t b, size_t e, size_t part) {
-        uLong c = crc32(0L, Z_NULL, 0);
-        for (size_t at = b; at < e;) { // crc32 takes a 32-bit length
-            const size_t m = std::min<size_t>(e - at, 1u << 30);
-            c = crc32(c, p + at, (uInt)m);
-            at += m;
-        }
-        crc[part] = (uint32_t)c;
-        len[part] = e - b;
-    });
-    uLong c = crc[0];
-    for (size_t i = 1; i < parts; ++i) c = crc32_combine(c, crc[i], (z_off_t)len[i]);
-    return (uint32_t)c;
-}
-} // namespace
 
 GzInflater::GzInflater(const unsigned char *data, size_t size) : DeflateStream(data, size), win(kWindow + kChunk + kSlack) {}
 
@@ -248,7 +225,7 @@ bool GzInflater::verify(const char *dst, size_t produced)
         const MemberEnd &m = ends[done];
         const size_t end = (size_t)(m.abs_off - call_start);
         const size_t n = end - seg;
-        const uint32_t c = parallel_crc(p + seg, n);
+        const uint32_t c = deflate_parallel_crc32(p + seg, n);
         const uint32_t whole = (uint32_t)crc32_combine(crc_running, c, (z_off_t)n);
         if (ok && (whole != m.crc || (uint32_t)(len_running + n) != m.isize)) {
             ok = false;
@@ -262,7 +239,7 @@ bool GzInflater::verify(const char *dst, size_t produced)
     ends.erase(ends.begin(), ends.begin() + (long)done);
     if (seg < produced) {
         const size_t n = produced - seg;
-        crc_running = (uint32_t)crc32_combine(crc_running, parallel_crc(p + seg, n), (z_off_t)n);
+        crc_running = (uint32_t)crc32_combine(crc_running, deflate_parallel_crc32(p + seg, n), (z_off_t)n);
         len_running += n;
     }
     return ok;

@@ -17,12 +17,13 @@
 
 #include "Deflate.h"
 
-class GzInflater : public DeflateStream {
+class GzInflater : public GzSource, public DeflateStream {
 public:
     GzInflater(const unsigned char *data, size_t size);
     // up to `want` decoded bytes into dst; fewer only at the end of the input or on an error
-    size_t read(char *dst, size_t want);
-    bool finished() const { return state == DONE || state == FAILED; }
+    size_t read(char *dst, size_t want) override;
+    bool finished() const override { return state == DONE || state == FAILED; }
+    const char *error() const override { return DeflateStream::error(); }
 
 private:
     enum State { MEMBER_HEADER, BLOCK_HEADER, STORED, HUFFMAN, MEMBER_TRAILER, DONE, FAILED };

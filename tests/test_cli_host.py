@@ -356,8 +356,9 @@ def test_bgzf_input_odd_files(hostcheck, workdir):
 
 
 def test_gzip_input_own_decoder_matches_zlib(hostcheck, workdir):
-    """Plain (single-stream) gzip input: the mapped-file decoder and zlib's gzread give the same
-    run, at several compression levels and with a second member appended."""
+    """Plain (single-stream) gzip input: the serial mapped-file decoder, the parallel one (forced
+    on this small file with 60 KB stretches) and zlib's gzread give the same run, at several
+    compression levels and with a second member appended."""
     import zlib
     d = str(workdir)
     text = open(os.path.join(cu.INPUTS, "test.fastq"), "rb").read() * 20
@@ -369,8 +370,8 @@ def test_gzip_input_own_decoder_matches_zlib(hostcheck, workdir):
         path = os.path.join(d, "own_l%d.fastq.gz" % level)
         open(path, "wb").write(blob)
         res = []
-        for tag, env in (("own", None), ("zlib", {"SICKLE_ZLIB_INFLATE": "1"})):
+        for tag, env in (("own", None), ("zlib", {"SICKLE_ZLIB_INFLATE": "1"}), ("par", {"SICKLE_GZ_CHUNK": "60000"})):
             o = os.path.join(d, "own_l%d_%s.fastq" % (level, tag))
             pr = cu.run_cli(hostcheck, workdir, ["se", "-f", path, "-t", "illumina", "-o", o, "-b", "2", "-a", "2"], env=env)
             res.append((pr.returncode, open(o, "rb").read(), cu.summary_block(pr.stdout.decode()), pr.stderr))
-        assert res[0] == res[1] and res[0][0] == 0 and len(res[0][1]) > 1000000
+        assert res[0] == res[1] == res[2] and res[0][0] == 0 and len(res[0][1]) > 1000000

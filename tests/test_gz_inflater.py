@@ -15,6 +15,7 @@ import pytest
 import cli_util as cu
 
 BIN = os.path.join(cu.ROOT, "tests", "cpu_shim", "inflate_check")
+PAR = os.path.join(cu.ROOT, "tests", "cpu_shim", "parallel_check")
 TEXT = open(os.path.join(cu.INPUTS, "test.fastq"), "rb").read()
 
 
@@ -96,3 +97,45 @@ def test_damaged_input_is_reported(inflate_check, tmp_path):
         else:
             assert b"error:" in pr.stderr
     assert silent_ok < 10
+
+
+def test_parallel_decoder_like_zlib(inflate_check, tmp_path):
+    """GzParallel on the same files, with chunks far smaller than in production so that every file
+    takes many rounds of several stretches: block starts guessed inside stored, fixed and dynamic
+    data, matches reaching into the unknown window, members ending mid-round."""
+    used = dropped = rounds = 0
+    for name, (blob, want) in cases().items():
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(blob)
+        for chunk, width, piece in ((4096, 8, 1 << 20), (30000, 3, 65537), (1 << 20, 4, 1 << 25), (70000, 1, 1 << 22)):
+            pr = subprocess.run([PAR, path, str(chunk), str(width), str(piece)], capture_output=True)
+            assert pr.returncode == 0 and pr.stdout == want, (name, chunk, width, pr.stderr[-200:])
+            f = pr.stderr.split()
+            rounds += int(f[1])
+            used += int(f[3])
+            dropped += int(f[5])
+    print("rounds", rounds, "stretches used", used, "dropped", dropped)
+    assert used > 1.5 * rounds  # (width-1 runs and chunks smaller than a block count one per round) the stretches really were joined, not decoded serially
+    assert dropped < used // 10
+
+
+def test_parallel_decoder_damaged_input(inflate_check, tmp_path):
+    rng = np.random.default_rng(19)
+    blob = gz(TEXT * 3)
+    path = str(tmp_path / "dmgp.gz")
+    clean = 0
+    for k in range(120):
+        b = bytearray(blob)
+        at = int(rng.integers(10, len(b)))
+        b[at] ^= 1 << int(rng.integers(0, 8))
+        if k % 3 == 0:
+            b = b[:at]
+        open(path, "wb").write(bytes(b))
+        pr = subprocess.run([PAR, path, "20000", "6"], capture_output=True)
+        assert pr.returncode in (0, 2), (k, at, pr.returncode)
+        if pr.returncode == 0:
+            assert pr.stdout == TEXT * 3, (k, at)
+            clean += 1
+        else:
+            assert b"error:" in pr.stderr
+    assert clean < 10
