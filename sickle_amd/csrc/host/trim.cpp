@@ -1,5 +1,6 @@
 #include "trim.h"
 
+#include "FqDeflate.h"
 #include "WorkerPool.h"
 
 #include <fcntl.h>
@@ -33,7 +34,8 @@ bool OutFile::open(const char *path, bool gz)
     fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     pos = 0;
     gzip = gz;
-    if (const char *e = getenv("SICKLE_GZ_LEVEL")) gz_level = std::max(1, std::min(9, atoi(e)));
+    gz_level = 6; // zlib's default, what the reference's gzopen(path, "w") uses
+    if (const char *e = getenv("SICKLE_GZ_LEVEL")) gz_level = strcmp(e, "fast") == 0 ? -1 : std::max(1, std::min(9, atoi(e)));
     struct stat st;
     seekable = fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
     return fd >= 0;
@@ -67,75 +69,11 @@ void OutFile::put(const char *p, size_t n)
     pos += n;
 }
 
-// ---- gzip output as BGZF (the blocked gzip of htslib's bgzip: SAM/BAM spec §4.1).  Every block
-// is a complete gzip member of at most 64 KiB whose header carries its own compressed size in a
-// "BC" extra field, so any gzip reader inflates the file as one stream (RFC 1952 §2.2) and a
-// BGZF-aware one -- GZReader here, bgzip -@, samtools -- finds the block boundaries without
-// inflating and works on the blocks in parallel.
-namespace {
-constexpr size_t kBgzfInput = 0xff00; // payload bytes per block, as bgzip
-constexpr size_t kBgzfMaxBlock = 0x10000;
-const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-struct Deflater { // one raw-deflate state per worker thread and level, reset per block
-    z_stream zs;
-    int level = -100;
-    bool live = false;
-    ~Deflater()
-    {
-        if (live) deflateEnd(&zs);
-    }
-    void prepare(int lvl)
-    {
-        if (live && lvl == level) {
-            deflateReset(&zs);
-            return;
-        }
-        if (live) deflateEnd(&zs);
-        memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, lvl, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-            error("deflateInit2 failed");
-            exit(EXIT_FAILURE);
-        }
-        live = true;
-        level = lvl;
-    }
-};
-
-// appends the block holding [p, p+n), n <= kBgzfInput, to out
-void bgzf_block(const char *p, size_t n, int level, std::string &out)
-{
-    static thread_local Deflater d;
-    const size_t at = out.size();
-    out.resize(at + kBgzfMaxBlock);
-    unsigned char *blk = (unsigned char *)out.data() + at;
-    memcpy(blk, kBgzfEof, 16);
-    size_t clen = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        d.prepare(attempt == 0 ? level : 0); // incompressible data: stored blocks always fit
-        d.zs.next_in = (Bytef *)p;
-        d.zs.avail_in = (uInt)n;
-        d.zs.next_out = blk + 18;
-        d.zs.avail_out = (uInt)(kBgzfMaxBlock - 18 - 8);
-        if (deflate(&d.zs, Z_FINISH) == Z_STREAM_END) {
-            clen = d.zs.total_out;
-            break;
-        }
-        if (attempt == 1) {
-            error("deflate failed");
-            exit(EXIT_FAILURE);
-        }
-    }
-    const uint32_t total = (uint32_t)(18 + clen + 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)p, (uInt)n);
-    blk[16] = (unsigned char)((total - 1) & 0xff);
-    blk[17] = (unsigned char)((total - 1) >> 8);
-    unsigned char *tail = blk + 18 + clen;
-    for (int i = 0; i < 4; ++i) tail[i] = (unsigned char)(crc >> (8 * i));
-    for (int i = 0; i < 4; ++i) tail[4 + i] = (unsigned char)((uint32_t)n >> (8 * i));
-    out.resize(at + total);
-}
-} // namespace
+// gzip output is written as BGZF (the blocked gzip of htslib's bgzip: SAM/BAM spec 4.1): every block
+// is a complete gzip member of at most 64 KiB whose header carries its own compressed size, so any
+// gzip reader inflates the file as one stream (RFC 1952 2.2) and a BGZF-aware one -- GZReader
+// here, bgzip -@, samtools -- finds the block boundaries without inflating and works on the
+// blocks in parallel.  The blocks are made by FqDeflate.cpp on the worker pool.
 
 void OutFile::write(const std::string &data)
 {
@@ -168,7 +106,7 @@ void OutFile::write_parts(const std::vector<std::string> &parts)
         std::vector<std::string> packed(groups);
         WorkerPool::instance().parallel_for(pieces.size(), groups, [&](size_t lo, size_t hi, size_t g) {
             packed[g].reserve((hi - lo) * (kBgzfInput / 3));
-            for (size_t i = lo; i < hi; ++i) bgzf_block(pieces[i].p, pieces[i].n, gz_level, packed[g]);
+            for (size_t i = lo; i < hi; ++i) bgzf_append_block(pieces[i].p, pieces[i].n, gz_level, packed[g]);
         });
         for (const std::string &m : packed) put(m.data(), m.size());
         return;
@@ -188,7 +126,7 @@ void OutFile::write_parts(const std::vector<std::string> &parts)
 void OutFile::close()
 {
     if (fd >= 0) {
-        if (gzip) put((const char *)kBgzfEof, sizeof kBgzfEof); // the empty block that ends a BGZF file
+        if (gzip) put((const char *)kBgzfEofBlock, sizeof kBgzfEofBlock); // the empty block that ends a BGZF file
         ::close(fd);
     }
     fd = -1;

@@ -44,7 +44,7 @@ private:
     int fd = -1;
     bool seekable = false; // a regular file: positional writes; pipes and devices get plain write(2)
     bool gzip = false;
-    int gz_level = -1; // zlib's default, what the reference's gzopen(path, "w") uses
+    int gz_level = 6;  // SICKLE_GZ_LEVEL=1..9: zlib at that level; =fast (-1): the FASTQ-shaped encoder (FqDeflate)
     uint64_t pos = 0;
 };
 

@@ -282,8 +282,10 @@ def test_gzip_output_is_bgzf_and_reads_back(hostcheck, workdir):
     big = os.path.join(d, "bgzf_src.fastq")
     open(big, "wb").write(open(src, "rb").read() * 40)  # several blocks per worker
     out, plain = os.path.join(d, "bz.fastq.gz"), os.path.join(d, "bz_plain.fastq")
-    for extra, o in ((["-g"], out), ([], plain)):
-        assert cu.run_cli(hostcheck, workdir, ["se", "-f", big, "-t", "illumina", "-o", o, "-a", "3"] + extra).returncode == 0
+    fast = os.path.join(d, "bz_fast.fastq.gz")
+    for extra, o, env in ((["-g"], out, None), ([], plain, None), (["-g"], fast, {"SICKLE_GZ_LEVEL": "fast"})):
+        assert cu.run_cli(hostcheck, workdir, ["se", "-f", big, "-t", "illumina", "-o", o, "-a", "3"] + extra, env=env).returncode == 0
+    assert gzip.decompress(open(fast, "rb").read()) == open(plain, "rb").read() and _walk_bgzf(open(fast, "rb").read())[-1] == 0
     blob = open(out, "rb").read()
     sizes = _walk_bgzf(blob)
     assert sizes[-1] == 0 and len(sizes) > 20 and max(sizes) <= 0xff00

@@ -16,6 +16,7 @@ import cli_util as cu
 
 BIN = os.path.join(cu.ROOT, "tests", "cpu_shim", "inflate_check")
 PAR = os.path.join(cu.ROOT, "tests", "cpu_shim", "parallel_check")
+BGZF = os.path.join(cu.ROOT, "tests", "cpu_shim", "bgzf_check")
 TEXT = open(os.path.join(cu.INPUTS, "test.fastq"), "rb").read()
 
 
@@ -139,3 +140,43 @@ def test_parallel_decoder_damaged_input(inflate_check, tmp_path):
         else:
             assert b"error:" in pr.stderr
     assert clean < 10
+
+
+def test_fast_encoder_round_trips(inflate_check, tmp_path):
+    """FqDeflate (SICKLE_GZ_LEVEL=fast) on FASTQ and on everything else a block may hold: each file
+    -> BGZF -> zlib and both of this repo's decoders must give the bytes back.  Degenerate blocks:
+    empty, one byte, one symbol only, incompressible (stored fallback), no newline at all, very
+    long lines (the line four up is out of the window), counts skewed enough to need the 15-bit
+    code length limit."""
+    rng = np.random.default_rng(23)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    skew = b"".join(bytes([65 + i]) * f for i, f in enumerate(fib))  # Fibonacci counts: deepest possible tree
+    files = {
+        "fastq": TEXT,
+        "fastq_crlf": TEXT[:200000].replace(b"\n", b"\r\n"),
+        "empty": b"",
+        "one": b"x",
+        "same": b"a" * 200000,
+        "random": rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(),
+        "noline": rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 200000).tobytes(),
+        "longlines": b"\n".join(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 40000).tobytes() for _ in range(8)),
+        "fibonacci": bytes(rng.permutation(np.frombuffer(skew, dtype=np.uint8))),
+        "headers_only": b"".join(b"@M0:%d:FC:1:%d:%d:%d 1:N:0:ACGT\n" % (i % 7, 1100 + i // 999, 9 * i % 30000, 13 * i % 2500) for i in range(9000)),
+    }
+    for name, data in files.items():
+        src = str(tmp_path / (name + ".txt"))
+        open(src, "wb").write(data)
+        for level in ("-1", "1"):
+            pr = subprocess.run([BGZF, src, level], capture_output=True)
+            assert pr.returncode == 0, (name, pr.stderr)
+            blob = pr.stdout
+            assert gzip.decompress(blob) == data, (name, level)
+            gzp = str(tmp_path / (name + ".gz"))
+            open(gzp, "wb").write(blob)
+            for tool, args in ((inflate_check, []), (PAR, ["30000", "4"])):
+                back = subprocess.run([tool, gzp] + args, capture_output=True)
+                assert back.returncode == 0 and back.stdout == data, (name, level, tool, back.stderr[-200:])
+        if name in ("fastq", "headers_only", "same"):
+            assert len(blob) < 0.6 * len(data)
