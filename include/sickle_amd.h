@@ -164,8 +164,10 @@ int sk_trim_batch(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, s
 int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *batch, sk_cut *out);
 int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 
-/* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile),
- * 2 = general (wave per read), 3 = tiled over a segmented batch.  For tests and bench labels. */
+/* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
+ * 2 = general (wave per read), 3 = tiled over a segmented batch, 4 = tiled with the tile staged
+ * through registers (equal lengths, no sequence buffer, row stride 72..160).  For tests and bench
+ * labels. */
 int sk_kernel_for(const sk_batch *batch);
 
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */

@@ -345,7 +345,11 @@ int sk_kernel_for(const sk_batch *batch)
 {
     if (!batch) return 0;
     if (batch->tiles) return 3;
-    return tile_eligible(batch) ? 1 : 2;
+    if (!tile_eligible(batch)) return 2;
+    // uniform batches without a sequence buffer (no -n) and rows of 72..160 bytes: the tile comes in
+    // through the wave's registers instead of LDS-DMA
+    if (!batch->lengths && !batch->seq && sk_tile_is_staged(batch->stride, batch->read_len, 0)) return 4;
+    return 1;
 }
 
 const char *sk_kernel_name(int which)
@@ -354,6 +358,7 @@ const char *sk_kernel_name(int which)
     case 1: return "sk_scan_tile_kernel";
     case 2: return "sk_scan_wave_kernel";
     case 3: return "sk_scan_tile_kernel";
+    case 4: return "sk_scan_tile_staged_kernel";
     default: return "";
     }
 }

@@ -43,6 +43,7 @@ struct sk_scan_args {
 };
 
 // internal to libsickle_amd.so (not part of the C ABI)
+extern "C" __attribute__((visibility("hidden"))) int sk_tile_is_staged(uint32_t stride, uint32_t read_len, int has_seq);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
                                      int cu_count, hipStream_t stream);

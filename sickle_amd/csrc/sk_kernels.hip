@@ -194,6 +194,8 @@ __device__ __forceinline__ int tile_pieces(uint32_t bytes)
 
 } // namespace
 
+#define SK_STAGE_MIN 5  /* register-staged kernels exist for tiles of 5..10 KiB: row strides 72..160 */
+#define SK_STAGE_MAX 10
 typedef int sk_v4i __attribute__((ext_vector_type(4)));
 typedef int sk_v16i __attribute__((ext_vector_type(16)));
 typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
@@ -222,14 +224,24 @@ typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 // descriptor -- byte offset, row stride, read length, row count -- and is uniform inside, so it
 // takes the matrix path like a uniform batch (the band matrix is rebuilt when the length changes,
 // which in a sorted batch is rare); cuts are scattered to out[out_index[slot]].
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0, bool SEG = false>
-__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
-sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
-                    const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
-                    unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
-                    const uint32_t *__restrict__ out_index = nullptr)
+//
+// STAGE > 0 (uniform batches without -n whose tile fits STAGE KiB): the tile does not come in by
+// LDS-DMA but through the wave's own registers -- STAGE global_load_dwordx4 (nt) of the NEXT tile
+// are in flight while this tile is scanned, and are written to the LDS buffer (ds_write_b128, same
+// image as the DMA's) once the scan is over.  Plain loads stream faster than LDS-DMA on this
+// device (tools/probes/read_bw.hip: 7.0 against 6.5 TB/s), and the registers act as a second
+// buffer per wave without costing LDS.
+typedef unsigned sk_v4u __attribute__((ext_vector_type(4)));
+
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, bool SEG, int STAGE>
+__device__ __forceinline__ void
+sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                  const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
+                  unsigned long long *errword, const sk_scan_args &a, const sk_tile_dev *__restrict__ tiles,
+                  const uint32_t *__restrict__ out_index)
 {
     static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
+    static_assert(STAGE == 0 || (UNIFORM && !HAS_SEQ && NBUF == 1 && !SEG), "register staging: uniform batches, one buffer");
     static_assert(!SEG || (UNIFORM && MFMA && NBUF == 1), "segmented batches run the uniform matrix path, one buffer");
     // -n: NBUF == 2 keeps the quality and the sequence tile in two buffers (8 waves per CU);
     // NBUF == 1 runs both through ONE buffer, one after the other (16 waves per CU)
@@ -311,12 +323,31 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     };
     auto tile_off_of = [&](uint64_t t) -> uint64_t { return SEG ? tiles[t].byte_off : (t << 6) * stride; };
 
+    // register stage: piece p of a FULL tile (64 rows; 64*stride bytes, a multiple of 512) is the
+    // 16 bytes per lane at p KiB; STAGE = the number of pieces, the last one may be a half (its
+    // upper lanes repeat the tile's last 16 bytes: same data to the same place, no predication).
+    // The last tile of a batch, if it is not full, comes in by LDS-DMA like in the unstaged kernel.
+    sk_v4u stage[STAGE ? STAGE : 1];
+    const uint32_t full_bytes = 64u * stride;
+    auto stage_off = [&](int p) -> uint32_t {
+        const uint32_t off = (uint32_t)p * 1024u + (uint32_t)lane * 16u;
+        return p == STAGE - 1 ? min(off, full_bytes - 16u) : off;
+    };
+    auto tile_is_full = [&](uint64_t tt) -> bool { return ((tt + 1) << 6) <= a.n_reads; };
+
     uint64_t t = wave_global;
     if (t >= n_tiles) return;
 
     // prologue: Q(t) [and S(t)] in flight
     uint32_t cur_bytes = tile_bytes_of(t);
-    tile_to_lds(qual + tile_off_of(t), buf0, cur_bytes, lane);
+    bool cur_staged = STAGE && tile_is_full(t);
+    if (cur_staged) {
+#pragma unroll
+        for (int p = 0; p < STAGE; ++p)
+            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + tile_off_of(t) + stage_off(p)));
+    } else {
+        tile_to_lds(qual + tile_off_of(t), buf0, cur_bytes, lane);
+    }
     if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + tile_off_of(t), buf1, cur_bytes, lane);
     int len_next = 0;
     if (!UNIFORM) {
@@ -360,6 +391,24 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             tile = buf0;
             // outstanding, oldest first: Q(t), S(t) [, store(t-1) before them]
             wait_vmcnt(tile_pieces(cur_bytes));
+        } else if (STAGE) {
+            tile = buf0;
+            const bool next_staged = more && tile_is_full(tn) && ABLATE != 2;
+            if (cur_staged && (ABLATE != 2 || t == wave_global)) {
+                // piece by piece: into the LDS buffer, and the register is reloaded at once with the
+                // same piece of the next tile (of this tile again if there is no full next tile: a
+                // load nobody uses keeps the code free of branches and its wait counts exact)
+                const uint8_t *nsrc = qual + tile_off_of(next_staged ? tn : t);
+#pragma unroll
+                for (int p = 0; p < STAGE; ++p) {
+                    const uint32_t off = stage_off(p);
+                    *reinterpret_cast<sk_v4u *>(buf0 + off) = stage[p];
+                    stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + off));
+                }
+            } else if (!cur_staged) {
+                wait_vmcnt(0); // the ragged last tile, by DMA
+            }
+            cur_staged = next_staged;
         } else if (NBUF == 1 || ABLATE == 2) {
             tile = buf0;
             wait_vmcnt(0);
@@ -374,7 +423,7 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         if (ABLATE == 1) {
             const sk_cut_dev dummy{(int)row[0], (int)row[1]};
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (NBUF == 1 && more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
+            if (NBUF == 1 && more && (!STAGE || !cur_staged)) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
             if (active) out[r] = dummy;
             cur_bytes = next_bytes;
             continue;
@@ -651,9 +700,10 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 if (SEQ_SHARES) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane); // Q(t+1)
                 else tile_to_lds(seq + tile_off_of(tn), buf1, next_bytes, lane);             // S(t+1)
             }
-        } else if (NBUF == 1 && ABLATE != 2) {
+        } else if (NBUF == 1 && ABLATE != 2 && (!STAGE || (more && !cur_staged))) {
             // single buffer: every LDS read of this tile is done, refill it now -- the cut store
-            // below and the other waves of the CU cover the DMA latency
+            // below and the other waves of the CU cover the DMA latency.  (Staged kernel: only the
+            // ragged last tile of the batch takes this way.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
         }
@@ -672,6 +722,28 @@ sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur_bytes = next_bytes;
     }
+}
+
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0, bool SEG = false>
+__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
+sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                    const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
+                    unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
+                    const uint32_t *__restrict__ out_index = nullptr)
+{
+    sk_scan_tile_body<UNIFORM, HAS_SEQ, MFMA, NBUF, ABLATE, SEG, 0>(qual, seq, lengths, out, errword, a, tiles, out_index);
+}
+
+// the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
+// wave hold the scan state and the next tile, three waves per SIMD (12 per CU) at STAGE = 10
+template <int STAGE, int ABLATE = 0>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                           const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
+                           unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
+                           const uint32_t *__restrict__ out_index = nullptr)
+{
+    sk_scan_tile_body<true, false, true, 1, ABLATE, false, STAGE>(qual, seq, lengths, out, errword, a, tiles, out_index);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -796,10 +868,20 @@ int tile_nbuf_default()
     return v;
 }
 
+int tile_stage_default()
+{
+    // diagnostic override (A/B runs): SK_TILE_STAGE=0 keeps uniform batches on the LDS-DMA kernel
+    static const int v = [] {
+        const char *e = getenv("SK_TILE_STAGE");
+        return (e && *e == '0') ? 0 : 1;
+    }();
+    return v;
+}
+
 template <typename K>
 hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                               sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a, int cu_count,
-                              int per_cu_cap, hipStream_t stream)
+                              int per_cu_cap, hipStream_t stream, bool by_registers = false)
 {
     // single-wave workgroups (waves never synchronise with each other); as many per CU as the
     // 160 KiB of LDS and the 32-wave limit allow
@@ -807,6 +889,24 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
     if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
     if (per_cu > 16) per_cu = 16;
+    if (by_registers) {
+        // the staged kernels are bounded by their registers, not by LDS (the grid is persistent, so
+        // workgroups beyond what fits would only run as a second round): waves per SIMD = the 512
+        // registers of a lane's file over the kernel's count (allocated in eights), four SIMDs
+        static thread_local const void *asked = nullptr;
+        static thread_local int fits = 0;
+        if (asked != reinterpret_cast<const void *>(kern)) {
+            hipFuncAttributes fa;
+            int regs = 0;
+            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs = fa.numRegs;
+            if (regs <= 0) regs = 160;
+            asked = reinterpret_cast<const void *>(kern);
+            fits = 4 * (512 / ((regs + 7) & ~7));
+            if (fits < 4) fits = 4;
+            if (getenv("SK_DEBUG_LAUNCH")) fprintf(stderr, "[sk] staged kernel: %d registers -> %d workgroups per CU\n", regs, fits);
+        }
+        if (per_cu > fits) per_cu = fits;
+    }
     if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
     const uint64_t n_tiles = (a->n_reads + 63) >> 6;
     uint64_t grid = (uint64_t)cu_count * per_cu;
@@ -821,6 +921,15 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
 }
 
 } // namespace
+
+// does a uniform batch of this shape take the register-staged kernel?
+extern "C" __attribute__((visibility("hidden"))) int sk_tile_is_staged(uint32_t stride, uint32_t read_len, int has_seq)
+{
+    const uint32_t wu = read_len / 10 ? read_len / 10 : read_len;
+    const uint32_t pieces = (64u * stride + 1023u) >> 10;
+    return !has_seq && read_len > 0 && wu <= 65 && tile_nbuf_default() == 1 && tile_stage_default() && stride >= 16 &&
+           stride % 8 == 0 && pieces >= SK_STAGE_MIN && pieces <= SK_STAGE_MAX;
+}
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const uint8_t *qual, const uint8_t *seq, const uint32_t *lengths,
                                      sk_cut_dev *out, unsigned long long *errword, const sk_scan_args *a,
@@ -844,6 +953,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
         return SK_GO((sk_scan_tile_kernel<false, true, false, 2>), 2);
     }
     if (nbuf == 1) {
+        const uint32_t pieces = (64u * a->stride + 1023u) >> 10;
+        if (mfma && sk_tile_is_staged(a->stride, a->read_len, 0)) {
+#define SK_STAGED(P) case P: return launch_tile_kernel(sk_scan_tile_staged_kernel<P>, 1, qual, seq, lengths, out, errword, a, cu_count, 0, stream, true)
+            switch (pieces) {
+                SK_STAGED(5); SK_STAGED(6); SK_STAGED(7); SK_STAGED(8); SK_STAGED(9); SK_STAGED(10);
+            default: break;
+            }
+#undef SK_STAGED
+        }
         if (mfma) return SK_GO((sk_scan_tile_kernel<true, false, true, 1>), 1);
         if (uniform) return SK_GO((sk_scan_tile_kernel<true, false, false, 1>), 1);
         return SK_GO((sk_scan_tile_kernel<false, false, false, 1>), 1);
@@ -895,6 +1013,9 @@ extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cu
     case 101: return SK_GO((sk_scan_tile_kernel<true, false, true, 1, 1>), 1);
     case 102: return SK_GO((sk_scan_tile_kernel<true, false, true, 1, 2>), 1);
     case 110: return SK_GO((sk_scan_tile_kernel<true, false, false, 1, 0>), 1);
+    case 200: return SK_GO((sk_scan_tile_staged_kernel<10, 0>), 1);
+    case 201: return SK_GO((sk_scan_tile_staged_kernel<10, 1>), 1);
+    case 202: return SK_GO((sk_scan_tile_staged_kernel<10, 2>), 1);
     default: return hipErrorInvalidValue;
     }
 #undef SK_GO

@@ -43,7 +43,12 @@ def test_kernel_selection():
     q = np.zeros(4096, dtype=np.uint8)  # numpy data is 16/64-byte aligned
     assert q.ctypes.data % 16 == 0
     b = capi.Batch(q.ctypes.data, None, None, 152, 150, None, 10)
-    assert capi.lib().sk_kernel_for(b) == 1
+    assert capi.lib().sk_kernel_for(b) == 4  # equal lengths, no -n, rows of 72..160 bytes: register-staged tiles
+    b = capi.Batch(q.ctypes.data, q.ctypes.data, None, 152, 150, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 1  # with a sequence buffer (-n): LDS-DMA tiles
+    b = capi.Batch(q.ctypes.data, None, None, 264, 250, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 1  # longer rows
+    assert capi.lib().sk_kernel_name(4) == b"sk_scan_tile_staged_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 150, 150, None, 10)
     assert capi.lib().sk_kernel_for(b) == 2
     off = np.zeros(2, dtype=np.uint64)
