@@ -12,14 +12,22 @@ ctx = capi.Context(0, 1)
 s = torch.cuda.Stream(dev)
 
 
-def timeit(fn, reps=8):
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s); fn(); e1.record(s); s.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return ts[len(ts) // 2]
+_settled = False
+
+
+def timeit(fn, reps=30):
+    """Average of `reps` launches queued back to back (like bench.py), after the device's start-up
+    clock ramp (the first ~100 launches of a process: tools/probes/bench_times.py) and 5 warm-ups."""
+    global _settled
+    for _ in range(5 if _settled else 150):
+        fn()
+    s.synchronize()
+    _settled = True
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record(s); fn(); e1.record(s)
+    s.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
 
 
 def report(name, ms, n, algo_bytes):
