@@ -396,14 +396,15 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             const bool next_staged = more && tile_is_full(tn) && ABLATE != 2;
             if (cur_staged && (ABLATE != 2 || t == wave_global)) {
                 // piece by piece: into the LDS buffer, and the register is reloaded at once with the
-                // same piece of the next tile (of this tile again if there is no full next tile: a
-                // load nobody uses keeps the code free of branches and its wait counts exact)
+                // same piece of the next tile (of the first KiB of this tile again if there is no full
+                // next tile: loads nobody uses keep the code free of branches and its wait counts exact)
                 const uint8_t *nsrc = qual + tile_off_of(next_staged ? tn : t);
+                const uint32_t keep = next_staged ? ~0u : 1023u; // no next tile: every piece re-reads the first KiB
 #pragma unroll
                 for (int p = 0; p < STAGE; ++p) {
                     const uint32_t off = stage_off(p);
                     *reinterpret_cast<sk_v4u *>(buf0 + off) = stage[p];
-                    stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + off));
+                    stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + (off & keep)));
                 }
             } else if (!cur_staged) {
                 wait_vmcnt(0); // the ragged last tile, by DMA
