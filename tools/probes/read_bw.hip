@@ -64,6 +64,34 @@ __global__ __launch_bounds__(64) void read_tiles(const unsigned char *__restrict
     if (!WRITE && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[threadIdx.x] = make_uint2(1, 1);
 }
 
+// (e) as (d), but a wave takes GROUP consecutive tiles per round and writes their cut pairs as one
+// contiguous burst (GROUP x 512 bytes) afterwards
+template <int GROUP>
+__global__ __launch_bounds__(64) void read_tiles_grouped(const unsigned char *__restrict__ src, size_t n_tiles, uint2 *out)
+{
+    const size_t n_groups = n_tiles / GROUP;
+    for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        uint2 cuts[GROUP];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) {
+            const unsigned char *gp = src + (g * GROUP + k) * 9728;
+            v4u v[10];
+            v4u acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 10; ++p) {
+                unsigned off = p * 1024 + threadIdx.x * 16;
+                if (p == 9 && off > 9728 - 16) off = 9728 - 16;
+                v[p] = __builtin_nontemporal_load((const v4u *)(gp + off));
+            }
+#pragma unroll
+            for (int p = 0; p < 10; ++p) { acc.x ^= v[p].x; acc.y ^= v[p].y; acc.z ^= v[p].z; acc.w ^= v[p].w; }
+            cuts[k] = make_uint2(acc.x ^ acc.z, acc.y ^ acc.w);
+        }
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) out[(g * GROUP + k) * 64 + threadIdx.x] = cuts[k];
+    }
+}
+
 int main()
 {
     const size_t bytes = 1520000000ull / 9728 * 9728;
@@ -110,5 +138,10 @@ int main()
         snprintf(nm, sizeof nm, "tiles vgpr nt, 16 B x 32 lanes, %d waves/CU", per_cu);
         timeit(nm, [&] { hipLaunchKernelGGL((read_tiles<3, 1>), dim3(256 * per_cu), dim3(64), 0, 0, d, n_tiles, cuts); });
     }
+    timeit("tiles grouped x4, 2 KiB write bursts, 12 waves/CU", [&] { hipLaunchKernelGGL((read_tiles_grouped<4>), dim3(256 * 12), dim3(64), 0, 0, d, n_tiles, cuts); });
+    timeit("tiles grouped x8, 4 KiB write bursts, 12 waves/CU", [&] { hipLaunchKernelGGL((read_tiles_grouped<8>), dim3(256 * 12), dim3(64), 0, 0, d, n_tiles, cuts); });
+    timeit("tiles grouped x16, 8 KiB write bursts, 12 waves/CU", [&] { hipLaunchKernelGGL((read_tiles_grouped<16>), dim3(256 * 12), dim3(64), 0, 0, d, n_tiles, cuts); });
+    timeit("tiles vgpr nt, 8 B/lane written, 12 waves/CU (again)", [&] { hipLaunchKernelGGL((read_tiles<1, 1>), dim3(256 * 12), dim3(64), 0, 0, d, n_tiles, cuts); });
+    timeit("tiles vgpr nt, no writes, 12 waves/CU (again)", [&] { hipLaunchKernelGGL((read_tiles<0, 1>), dim3(256 * 12), dim3(64), 0, 0, d, n_tiles, cuts); });
     return 0;
 }
