@@ -9,22 +9,54 @@
 
 using namespace deflate_detail;
 
+// CRC-32 (the gzip polynomial, reflected 0xedb88320), eight bytes per step through eight tables
+// ("slicing by 8"); zlib 1.2.11's crc32 works four bytes at a time.
+namespace {
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables()
+    {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
+    }
+};
+const CrcTables crc_tables;
+
+uint32_t crc32_fast(const unsigned char *p, size_t n)
+{
+    const uint32_t(*t)[256] = crc_tables.t;
+    uint32_t c = 0xffffffffu;
+    while (n && ((uintptr_t)p & 7)) {
+        c = (c >> 8) ^ t[0][(c ^ *p++) & 0xff];
+        --n;
+    }
+    while (n >= 8) {
+        const uint64_t v = load64(p) ^ c;
+        c = t[7][v & 0xff] ^ t[6][(v >> 8) & 0xff] ^ t[5][(v >> 16) & 0xff] ^ t[4][(v >> 24) & 0xff] ^ t[3][(v >> 32) & 0xff] ^
+            t[2][(v >> 40) & 0xff] ^ t[1][(v >> 48) & 0xff] ^ t[0][v >> 56];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ t[0][(c ^ *p++) & 0xff];
+    return ~c;
+}
+} // namespace
+
 // CRC-32 of a large buffer on all host threads (slices combined with crc32_combine)
 uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n)
 {
-    if (n < (4u << 20)) return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+    if (n < (4u << 20)) return crc32_fast(p, n);
     WorkerPool &pool = WorkerPool::instance();
     const size_t parts = std::min<size_t>((size_t)pool.size() * 2, n / (1u << 20));
     std::vector<uint32_t> crc(parts);
     std::vector<size_t> len(parts);
     pool.parallel_for(n, parts, [&](size_t b, size_t e, size_t part) {
-        uLong c = crc32(0L, Z_NULL, 0);
-        for (size_t at = b; at < e;) { // crc32 takes a 32-bit length
-            const size_t m = std::min<size_t>(e - at, 1u << 30);
-            c = crc32(c, p + at, (uInt)m);
-            at += m;
-        }
-        crc[part] = (uint32_t)c;
+        crc[part] = crc32_fast(p + b, e - b);
         len[part] = e - b;
     });
     uLong c = crc[0];

@@ -487,7 +487,14 @@ size_t GzParallel::read(char *dst, size_t want)
     while (produced < want) {
         if (avail_at < round_out.size()) {
             const size_t n = std::min(round_out.size() - avail_at, want - produced);
-            memcpy(dst + produced, round_out.data() + avail_at, n);
+            if (n >= (8u << 20)) { // one core copies ~10 GB/s: a round is tens of MiB
+                const char *from = round_out.data() + avail_at;
+                char *to = dst + produced;
+                WorkerPool &pool = WorkerPool::instance();
+                pool.parallel_for(n, std::min<size_t>((size_t)pool.size(), n >> 20), [&](size_t lo, size_t hi, size_t) { memcpy(to + lo, from + lo, hi - lo); });
+            } else {
+                memcpy(dst + produced, round_out.data() + avail_at, n);
+            }
             avail_at += n;
             produced += n;
             continue;
