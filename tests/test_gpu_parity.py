@@ -348,3 +348,44 @@ def test_segmented_batches(sk_ctx):
     with pytest.raises(capi.RangeError) as ei:
         sk_ctx.trim_segmented(p, qs2, tiles2, oi2, ms2, seq=ss2)
     assert (ei.value.read, ei.value.pos, ei.value.ch) == (7_777, 3, 20)
+
+
+def test_register_staged_tiles(sk_ctx):
+    """The register-staged tile kernel (equal lengths, rows of 72..160 bytes): every stage size
+    (5..10 KiB tiles), batches of one read, just under / on / over a tile boundary, and one large
+    enough that every wave takes several tiles in turn (12 waves x 256 CUs x 64 reads = 196 608
+    per round) ending in a ragged tile; plus a range error deep inside such a batch, which must be
+    the reference's (read, position, char)."""
+    rng = np.random.default_rng(2718)
+    for stride in range(72, 161, 8):
+        L = stride - int(rng.integers(0, 8)) if stride > 72 else 70
+        b = capi.Batch(0, None, None, stride, L, None, 10)
+        assert capi.lib().sk_kernel_for(b) == 4, stride
+        for n in (1, 63, 64, 65, 129, 1000, 3 * 196608 + 77 if stride in (104, 152) else 5000):
+            qt = ("sanger", "illumina", "solexa")[(stride // 8 + n) % 3]
+            lo, hi = {"sanger": (33, 74), "solexa": (59, 105), "illumina": (64, 105)}[qt]
+            mid = int(rng.integers(lo + 6, hi - 6))
+            qual = np.clip(mid + rng.integers(-16, 17, size=(n, L), dtype=np.int16), lo, hi).astype(np.uint8)
+            drop = rng.integers(0, L + 1, size=n)
+            qual[np.arange(L)[None, :] >= drop[:, None]] = lo + 1
+            qs = synth.pack_fixed(qual, stride)
+            q, l, x = int(rng.integers(0, 42)), int(rng.integers(0, L)), int(rng.integers(0, 2))
+            p, po = both_params(qt, q, l, x, 0)
+            want, err = ob.oracle_trim_batch(po, qs, None, stride=stride, read_len=L, n_reads=n)
+            assert err is None
+            got = sk_ctx.trim_batch(p, qs, stride=stride, read_len=L, n_reads=n)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert bad.size == 0, (stride, L, n, qt, q, l, x, bad[:4], got[bad[:4]], want[bad[:4]])
+    # a bad char in the last full tile of a long batch and one in its ragged tail
+    n, stride, L = 2 * 196608 + 40, 152, 150
+    qs = np.full((n, stride), 75, dtype=np.uint8)
+    qs[n - 3, 5] = 20
+    qs[n - 70, 149] = 31
+    p, po = both_params("sanger", 20, 20, 0, 0)
+    with pytest.raises(capi.RangeError) as ei:
+        sk_ctx.trim_batch(p, qs.reshape(-1), stride=stride, read_len=L, n_reads=n)
+    assert (ei.value.read, ei.value.pos, ei.value.ch) == (n - 70, 149, 31)
+    qs[n - 70, 149] = 75
+    with pytest.raises(capi.RangeError) as ei:
+        sk_ctx.trim_batch(p, qs.reshape(-1), stride=stride, read_len=L, n_reads=n)
+    assert (ei.value.read, ei.value.pos, ei.value.ch) == (n - 3, 5, 20)
