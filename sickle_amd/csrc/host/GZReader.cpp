@@ -271,7 +271,11 @@ bool GZReader::fill()
         } else {
             char *dst = pending.data() + old;
             const uint64_t base = file_pos;
-            const size_t slices = (size_t)std::min<uint64_t>(8, (want + (4u << 20) - 1) / (4u << 20));
+            static const uint64_t max_slices = [] {
+                const char *e = getenv("SICKLE_READ_SLICES");
+                return e && atoi(e) > 0 ? (uint64_t)atoi(e) : (uint64_t)8;
+            }();
+            const size_t slices = (size_t)std::min<uint64_t>(max_slices, (want + (4u << 20) - 1) / (4u << 20));
             std::atomic<bool> failed{false};
             WorkerPool::instance().parallel_for((size_t)want, slices, [&](size_t b, size_t e, size_t) {
                 size_t done = b;

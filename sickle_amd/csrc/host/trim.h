@@ -8,6 +8,7 @@
 #ifndef SICKLE_TRIM_H
 #define SICKLE_TRIM_H
 
+#include <sys/resource.h>
 #include <zlib.h>
 
 #include <chrono>
@@ -82,8 +83,11 @@ public:
         }();
         if (!on) return;
         static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[mark] %7.3f s  %s\n",
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[mark] %7.3f s  %s  (cpu so far: user %.2f s, system %.2f s)\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what,
+                ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
     }
 };
 
