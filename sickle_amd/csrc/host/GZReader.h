@@ -2,7 +2,7 @@
 //
 // Role of reference src/GZReader.{h,cpp} and src/Batch.{h,cpp}; written fresh.  The reference
 // reads line by line with gzgets into one heap string per line; this reader pulls large blocks
-// (read(2) for plain files; gzip decoded from the mapped file on all host threads (GzParallel), or
+// (plain regular files are mapped and indexed in place, pipes read(2); gzip decoded from the mapped file on all host threads (GzParallel), or
 // through zlib's gzread when the input is not a regular file; and for BGZF -- blocked gzip as written by bgzip and by this
 // program's own -g -- all blocks of a chunk inflated at once on the host threads)
 // straight into the batch's own text buffer, finds
@@ -32,16 +32,28 @@
 #include <vector>
 
 // growable byte buffer without value-initialisation (a std::vector<char> would zero every block
-// before read() overwrites it)
+// before read() overwrites it); or a borrowed view of bytes someone else owns (a mapped file)
 class RawBuf {
 public:
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    ~RawBuf()
+    {
+        if (!borrowed) free(p);
+    }
     char *data() { return p; }
     const char *data() const { return p; }
     size_t size() const { return n; }
+    bool is_borrowed() const { return borrowed; }
+    void borrow(const char *from, size_t bytes) // a view; the owner outlives it.  Never written through.
+    {
+        if (!borrowed) free(p);
+        p = const_cast<char *>(from);
+        n = bytes;
+        cap = (size_t)-1;
+        borrowed = true;
+    }
     void reserve(size_t c)
     {
         if (c <= cap) return;
@@ -57,11 +69,13 @@ public:
         std::swap(p, o.p);
         std::swap(n, o.n);
         std::swap(cap, o.cap);
+        std::swap(borrowed, o.borrowed);
     }
 
 private:
     char *p = nullptr;
     size_t n = 0, cap = 0;
+    bool borrowed = false;
 };
 
 // One batch: the text of its lines and where each line sits.  Role of reference src/Batch.h.
@@ -111,6 +125,7 @@ private:
     size_t map_len = 0;
     int fd = -1;           // plain input: read(2) / parallel pread(2), no zlib copy
     bool regular = false;  // a regular file of known size: blocks are pread in parallel slices
+    bool mapped = false;   // ... or, by default, the file is mapped and batches are views of the mapping
     bool bgzf = false;     // gzip input whose members carry their size (BGZF): inflated in parallel
     RawBuf cbuf;           // compressed bytes of the current BGZF chunk
     uint64_t file_size = 0, file_pos = 0;

@@ -8,7 +8,10 @@
 
 WorkerPool &WorkerPool::instance()
 {
-    static WorkerPool pool([] {
+    // never destroyed: the error paths leave through exit(1) like the reference's, with the other
+    // pipeline threads still running, and a pool torn down by the static destructors under them
+    // would be freed memory in use (ThreadSanitizer found exactly that)
+    static WorkerPool &pool = *new WorkerPool([] {
         if (const char *e = getenv("SICKLE_HOST_THREADS")) {
             const int n = atoi(e);
             if (n >= 1) return n;

@@ -18,6 +18,9 @@ HOSTCHECK_BIN = os.path.join(ROOT, "tests", "cpu_shim", "sickle_hostcheck")  # o
 
 
 def build_hostcheck():
+    # SICKLE_HOSTCHECK_BIN: a sanitizer build of the same sources, run through the same tests
+    if os.environ.get("SICKLE_HOSTCHECK_BIN"):
+        return os.environ["SICKLE_HOSTCHECK_BIN"]
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpu_shim")], check=True)
     return HOSTCHECK_BIN
 
