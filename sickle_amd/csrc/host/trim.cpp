@@ -117,13 +117,13 @@ void OutFile::write_parts(const std::vector<std::string> &parts)
     }
     std::vector<uint64_t> at(parts.size() + 1, pos);
     for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].size();
-    // two writers per file by default (the files of a batch are written side by side as well):
-    // concurrent writers to ONE file queue up on its page-cache locks -- measured on tmpfs, 10 M
-    // pairs: 1 writer 0.49 s for the stage and 4.7 s of system time in the run, 8 writers 0.60 s
-    // and 10.5 s; the wall time of the run is the same within noise (tools/probes/ab_env.py)
+    // one writer per file by default (the files of a batch are still written side by side):
+    // concurrent writers to ONE file queue up on its page-cache locks.  Measured on tmpfs, 10 M
+    // pairs, whole run (tools/probes/ab_env.py): 1 writer 1.77 s, 2: 2.12 s, 4: 2.08 s, 8: 1.98 s,
+    // and a quarter of the system time.
     static const size_t writers = [] {
         const char *e = getenv("SICKLE_WRITE_SLICES");
-        return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)2;
+        return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1;
     }();
     WorkerPool::instance().parallel_for(parts.size(), std::min(parts.size(), writers), [&](size_t lo, size_t hi, size_t) {
         for (size_t i = lo; i < hi; ++i) pwrite_all(fd, parts[i].data(), parts[i].size(), at[i]);
