@@ -4,7 +4,9 @@
 #ifndef SICKLE_FQENTRY_H
 #define SICKLE_FQENTRY_H
 
+#include <cstdlib>
 #include <string_view>
+#include <type_traits>
 
 #include "GZReader.h"
 
@@ -22,6 +24,34 @@ public:
     std::string_view qual;
     int position; // 1-based record number, only used in error messages
     void validate() const; // exit(EXIT_FAILURE) with the reference's messages on a malformed record
+};
+
+// An array of trivially copyable records whose elements are NOT initialised on resize: every
+// element is written exactly once by whoever fills it (in parallel), and value-initialising a
+// hundred megabytes of them first on one thread was a fifth of the framing stage.
+template <typename T> class RawVec {
+public:
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    void resize(size_t count)
+    {
+        static_assert(std::is_trivially_copyable<T>::value && std::is_trivially_destructible<T>::value, "raw storage");
+        free(p);
+        p = count ? (T *)malloc(count * sizeof(T)) : nullptr;
+        if (count && !p) abort();
+        n = count;
+    }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+
+private:
+    T *p = nullptr;
+    size_t n = 0;
 };
 
 #endif

@@ -251,7 +251,7 @@ void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bo
     }
 }
 
-void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
+void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
 {
     ensure_device();
     Slot &s = slots[(size_t)slot];
@@ -268,11 +268,29 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     size_t total_len = 0, max_len = 0;
     bool uniform = true;
     const size_t len0 = n ? reads[0].qual.length() : 0;
-    for (const FQEntry &r : reads) {
-        const size_t l = r.qual.length();
-        total_len += l;
-        if (l > max_len) max_len = l;
-        uniform = uniform && l == len0;
+    WorkerPool &pool = WorkerPool::instance();
+    const size_t parts = (size_t)pool.size() * 4;
+    {
+        struct Acc {
+            size_t total = 0, longest = 0;
+            bool same = true;
+        };
+        std::vector<Acc> acc(parts);
+        pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t part) {
+            Acc a;
+            for (size_t i = lo; i < hi; ++i) {
+                const size_t l = reads[i].qual.length();
+                a.total += l;
+                if (l > a.longest) a.longest = l;
+                a.same = a.same && l == len0;
+            }
+            acc[part] = a;
+        });
+        for (const Acc &a : acc) {
+            total_len += a.total;
+            if (a.longest > max_len) max_len = a.longest;
+            uniform = uniform && a.same;
+        }
     }
     // stride: a multiple of 8 with an ODD number of 8-byte units, so that the per-lane row walks of
     // the tiled kernel (ds_read_b64 at lane*stride) spread over all LDS banks; an even count
@@ -285,8 +303,6 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     const bool tiled = n > 0 && max_len > 0 && stride_for(max_len) <= SK_TILE_MAX_STRIDE;
     const bool segmented = tiled && !uniform;
     const bool need_seq = trunc_n != 0;
-    WorkerPool &pool = WorkerPool::instance();
-    const size_t parts = (size_t)pool.size() * 4;
 
     sk_batch b;
     memset(&b, 0, sizeof b);
@@ -375,7 +391,7 @@ void Abstract_Trimmer::submit_scan(int slot, const std::vector<FQEntry> &reads)
     }
 }
 
-const cutsites *Abstract_Trimmer::wait_scan(int slot, const std::vector<FQEntry> &reads)
+const cutsites *Abstract_Trimmer::wait_scan(int slot, const RawVec<FQEntry> &reads)
 {
     static_assert(sizeof(cutsites) == sizeof(sk_cut), "cutsites must match the C ABI's sk_cut");
     sk_err e;

@@ -151,17 +151,17 @@ protected:
     void close_device();
     // packs the quality (and, with -n, sequence) bytes of `reads` into the slot's pinned buffers
     // and enqueues H2D + scan + D2H; returns at once
-    void submit_scan(int slot, const std::vector<FQEntry> &reads);
+    void submit_scan(int slot, const RawVec<FQEntry> &reads);
     // blocks until the slot is done; on an out-of-range quality prints the reference's message
     // (src/trim.cpp:130-135) and exits 1.  The cut array stays valid until the slot is reused.
-    const cutsites *wait_scan(int slot, const std::vector<FQEntry> &reads);
+    const cutsites *wait_scan(int slot, const RawVec<FQEntry> &reads);
 
     // Frames records [0, n) of a batch on all host threads: record i is made from the four lines
     // starting at line first_line(i) with position position(i).  If any record is malformed the
     // FIRST one in order is re-validated on the calling thread, which prints the reference's
     // messages and exits (src/FQEntry.cpp:53-97).
     template <typename LineOf, typename PosOf>
-    static void frame_records(std::vector<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
+    static void frame_records(RawVec<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
                               PosOf position, size_t dst0 = 0, size_t dst_step = 1);
 
     // Runs reader->get_batch_buffering_lines() ahead of the consumer on its own thread: batches
@@ -213,7 +213,7 @@ private:
 #include "WorkerPool.h"
 
 template <typename LineOf, typename PosOf>
-void Abstract_Trimmer::frame_records(std::vector<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
+void Abstract_Trimmer::frame_records(RawVec<FQEntry> &reads, const Batch &batch, size_t n, LineOf first_line,
                                      PosOf position, size_t dst0, size_t dst_step)
 {
     WorkerPool &pool = WorkerPool::instance();

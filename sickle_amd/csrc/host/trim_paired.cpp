@@ -409,7 +409,7 @@ int Trim_Paired::trim_main()
                 // mate 1 first, then mate 2: a malformed mate 1 anywhere is reported before any
                 // mate 2 problem only if it comes first in the reference's own order, which
                 // alternates -- so check the pairs in that order afterwards
-                std::vector<FQEntry> &rd = w->reads;
+                RawVec<FQEntry> &rd = w->reads;
                 WorkerPool &pool = WorkerPool::instance();
                 const size_t parts = (size_t)pool.size() * 4;
                 std::vector<size_t> first_bad(parts, (size_t)-1);

@@ -16,7 +16,7 @@ public:
 protected:
     struct Work {
         Batch *batch = nullptr, *batch2 = nullptr;
-        std::vector<FQEntry> reads; // mate 1 of pair k at 2k, mate 2 at 2k+1 (the reference's scan order)
+        RawVec<FQEntry> reads; // mate 1 of pair k at 2k, mate 2 at 2k+1 (the reference's scan order)
         std::vector<cutsites> cuts;
     };
     int init_streams();

@@ -18,7 +18,7 @@ public:
 private:
     struct Work {
         Batch *batch = nullptr;
-        std::vector<FQEntry> reads;
+        RawVec<FQEntry> reads;
         std::vector<cutsites> cuts;
     };
     // builds the output text of one batch, in pieces, in file order; updates the counters
