@@ -47,6 +47,8 @@ uint32_t crc32_fast(const unsigned char *p, size_t n)
 }
 } // namespace
 
+uint32_t deflate_crc32(const unsigned char *p, size_t n) { return crc32_fast(p, n); }
+
 // CRC-32 of a large buffer on all host threads (slices combined with crc32_combine)
 uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n)
 {

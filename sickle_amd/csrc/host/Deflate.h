@@ -36,7 +36,8 @@ inline void store16(unsigned char *p, uint16_t v) { memcpy(p, &v, 2); }
 
 } // namespace deflate_detail
 
-uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n);
+uint32_t deflate_crc32(const unsigned char *p, size_t n);          // on the calling thread
+uint32_t deflate_parallel_crc32(const unsigned char *p, size_t n); // large buffers: on all host threads
 
 // what GZReader pulls decoded bytes from
 class GzSource {

@@ -19,7 +19,12 @@ constexpr uint16_t kUnknown = 256; // symbol 256 + j = byte j of the window befo
 // boundary it stopped at, decoded into 16-bit symbols.
 class GzParallel::Stretch : public DeflateStream {
 public:
-    enum End { NOTHING, AT_STOP, AT_LIMIT, MEMBER_END, FAILED, DROPPED };
+    enum End { NOTHING, AT_STOP, AT_LIMIT, STREAM_END, FAILED, DROPPED };
+    struct Mark { // a gzip member ended after n_sym symbols of this stretch; its trailer said:
+        size_t n_sym;
+        uint32_t crc, isize;
+    };
+    std::vector<Mark> marks;
     Stretch(const unsigned char *d, size_t n) : DeflateStream(d, n), base(d), total(n) {}
 
     std::vector<uint16_t> sym; // [window: known bytes or placeholders | decoded symbols]
@@ -52,15 +57,25 @@ public:
             if (!plausible(p)) continue;
             seek_bits(p);
             n_sym = 0;
-            if (next_block() == 1 && lit_complete && (dist_complete || dist_codes <= 1) && huffman_block() && !last_block) {
-                boundary_bit = bitpos();
-                header_kind = next_block();
-                if (header_kind >= 0) {
-                    header_ready = true;
-                    begin_bit = p;
-                    return true;
+            if (next_block() == 1 && lit_complete && (dist_complete || dist_codes <= 1) && huffman_block()) {
+                // what follows must parse too: another block header, or (after a final block) the
+                // member's trailer and the next member's gzip header
+                if (last_block) {
+                    if (hop_member() == 1) {
+                        begin_bit = p;
+                        return true;
+                    }
+                } else {
+                    boundary_bit = bitpos();
+                    header_kind = next_block();
+                    if (header_kind >= 0) {
+                        header_ready = true;
+                        begin_bit = p;
+                        return true;
+                    }
                 }
             }
+            marks.clear();
             err = nullptr;
             end = NOTHING;
         }
@@ -84,7 +99,12 @@ public:
             }
             if (kind < 0) return stop(FAILED, p);
             if (!(kind == 0 ? stored_block() : huffman_block())) return stop(end == DROPPED ? DROPPED : FAILED, p);
-            if (last_block) return stop(MEMBER_END, bitpos());
+            if (last_block) {
+                const uint64_t e = bitpos();
+                const int hop = hop_member();
+                if (hop < 0) return stop(FAILED, e);
+                if (hop == 0) return stop(STREAM_END, e);
+            }
         }
     }
 
@@ -107,6 +127,27 @@ private:
         end_bit = at;
     }
 
+    // after a final block: notes the member's trailer and steps over the next member's header.
+    // 1 = at the first block of the next member, 0 = no further member, -1 = damaged
+    int hop_member()
+    {
+        const size_t at = (size_t)((bitpos() + 7) / 8);
+        if (total - at < 8) return fail("unexpected end of file"), -1;
+        const unsigned char *t = base + at;
+        Mark m;
+        m.n_sym = n_sym;
+        m.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        m.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        marks.push_back(m);
+        in = base + at + 8;
+        bitbuf = 0;
+        bitcnt = 0;
+        last_block = false;
+        bool none = false;
+        if (!gzip_header(false, &none)) return -1;
+        return none ? 0 : 1;
+    }
+
     void prepare()
     {
         if (sym.size() < kWindow + (1u << 20)) sym.resize(kWindow + (1u << 20));
@@ -114,6 +155,7 @@ private:
         end = NOTHING;
         header_ready = false;
         err = nullptr;
+        marks.clear();
     }
 
     void seek_bits(uint64_t p)
@@ -133,7 +175,7 @@ private:
         const unsigned char *q = base + (p >> 3);
         const int bit = (int)(p & 7);
         const uint64_t v = load64(q) >> bit;
-        if ((v & 7) != 4) return false; // BFINAL 0, BTYPE 2
+        if ((v & 6) != 4) return false; // BTYPE 2 (BFINAL either way: small members are one final block)
         if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) return false;
         const int hclen = (int)((v >> 13) & 15) + 4;
         const uint64_t w = load64(q + 4) >> bit; // bits 32.. of the header
@@ -442,39 +484,54 @@ bool GzParallel::decode_round()
         });
     window = win[chain.size()];
 
-    if (total) {
-        const uint32_t c = deflate_parallel_crc32((const unsigned char *)round_out.data(), total);
-        crc_running = (uint32_t)crc32_combine(crc_running, c, (z_off_t)total);
-        len_running += total;
+    // CRC-32 and length of every member that ended in this round; the open member's running values
+    // go on to the next round.  Segments = the stretches of output between member ends.
+    {
+        struct Seg {
+            size_t from, to;
+            bool closes; // a member ends at `to`
+            uint32_t crc, isize, got;
+        };
+        std::vector<Seg> segs;
+        size_t from = 0;
+        for (size_t i = 0; i < chain.size(); ++i)
+            for (const Stretch::Mark &m : stretches[(size_t)chain[i]]->marks) {
+                const size_t to = offset[i] + m.n_sym;
+                segs.push_back({from, to, true, m.crc, m.isize, 0});
+                from = to;
+            }
+        if (from < total) segs.push_back({from, total, false, 0, 0, 0});
+        const unsigned char *bytes = (const unsigned char *)round_out.data();
+        if (segs.size() <= 2) { // long members: each segment on all threads
+            for (Seg &g : segs) g.got = deflate_parallel_crc32(bytes + g.from, g.to - g.from);
+        } else { // many short members: the segments side by side
+            pool.parallel_for(segs.size(), std::min(segs.size(), (size_t)pool.size() * 4), [&](size_t lo, size_t hi, size_t) {
+                for (size_t q = lo; q < hi; ++q) segs[q].got = deflate_crc32(bytes + segs[q].from, segs[q].to - segs[q].from);
+            });
+        }
+        for (const Seg &g : segs) {
+            const size_t n = g.to - g.from;
+            crc_running = (uint32_t)crc32_combine(crc_running, g.got, (z_off_t)n);
+            len_running += n;
+            if (g.closes) {
+                if (!err && crc_running != g.crc) err = "incorrect data check";
+                else if (!err && (uint32_t)len_running != g.isize) err = "incorrect length check";
+                crc_running = 0;
+                len_running = 0;
+            }
+        }
+        if (err) done = true;
     }
     const Stretch &tail = *stretches[(size_t)chain.back()];
     switch (tail.end) {
     case Stretch::AT_LIMIT:
         start_bit = tail.end_bit;
         break;
-    case Stretch::MEMBER_END: {
-        const size_t at = (size_t)((tail.end_bit + 7) / 8);
-        if (size - at < 8) {
-            err = "unexpected end of file";
-            done = true;
-            break;
-        }
-        const unsigned char *t = data + at;
-        const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-        const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-        if (crc != crc_running) {
-            err = "incorrect data check";
-            done = true;
-        } else if (isize != (uint32_t)len_running) {
-            err = "incorrect length check";
-            done = true;
-        }
-        start_bit = (uint64_t)(at + 8) * 8;
-        at_member_start = true;
+    case Stretch::STREAM_END: // the last member is complete and nothing that is a gzip member follows
+        done = true;
         break;
-    }
     default: // FAILED on the chain: the data is damaged there (what was decoded before it is kept)
-        err = tail.problem() ? tail.problem() : "invalid deflate data";
+        if (!err) err = tail.problem() ? tail.problem() : "invalid deflate data";
         done = true;
         break;
     }
