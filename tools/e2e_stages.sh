@@ -11,5 +11,5 @@ PY
 for i in 1 2; do
   T0=$(date +%s.%N); SICKLE_STAGE_TIMES=1 ./sickle_amd/sickle pe -f $D/R1.fastq -r $D/R2.fastq -t sanger -o $D/o1 -p $D/o2 -s $D/os -a 1 2>&1 >/dev/null | grep -v 'framed\|submitted' | tr '\n' ';' | sed 's/\[mark\]//g; s/  */ /g'; echo
 done
-T0=$(date +%s.%N); SICKLE_STAGE_TIMES=1 ./sickle_amd/sickle se -f $D/R1.fastq -t sanger -o $D/o1 -a 1 2>&1 >/dev/null | tr '\n' ' '; echo "SE wall $(echo "$(date +%s.%N) - $T0" | bc) s"
+echo "SE:"; SICKLE_STAGE_TIMES=1 ./sickle_amd/sickle se -f $D/R1.fastq -t sanger -o $D/se_out -a 1 2>&1 >/dev/null | grep -E "stage|closed|device open" | tr '\n' ';'; echo
 rm -rf "$D"
