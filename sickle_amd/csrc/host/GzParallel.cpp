@@ -31,7 +31,8 @@ public:
     size_t n_sym = 0;
     uint64_t begin_bit = 0, end_bit = 0;
     End end = NOTHING;
-    size_t cap_symbols = SIZE_MAX;
+    size_t cap_symbols = SIZE_MAX;  // guessed starts: beyond this the stretch is taken to decode nonsense
+    size_t soft_cap = SIZE_MAX;     // any stretch: stop at the next block boundary beyond this
 
     uint64_t bitpos() const { return (uint64_t)(in - base) * 8 - (uint64_t)bitcnt; }
     const char *problem() const { return err; }
@@ -90,6 +91,9 @@ public:
             const uint64_t p = header_ready ? boundary_bit : bitpos();
             if (p >= limit) return stop(AT_LIMIT, p);
             if (std::binary_search(stops.begin(), stops.end(), p)) return stop(AT_STOP, p);
+            // very compressible data (runs): end the stretch at this boundary rather than let its
+            // symbols grow without bound; the next round starts here
+            if (n_sym >= soft_cap) return stop(AT_LIMIT, p);
             int kind;
             if (header_ready) {
                 kind = header_kind;
@@ -409,6 +413,7 @@ bool GzParallel::decode_round()
     std::vector<char> valid((size_t)n, 0);
     valid[0] = 1;
     stretches[0]->start_known(start_bit, window.data());
+    for (int k = 0; k < n; ++k) stretches[(size_t)k]->soft_cap = std::max<size_t>(chunk * 24, 16u << 20);
     if (n > 1)
         pool.parallel_for((size_t)n - 1, (size_t)n - 1, [&](size_t lo, size_t hi, size_t) {
             for (size_t k = lo + 1; k < hi + 1; ++k) {

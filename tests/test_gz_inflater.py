@@ -65,6 +65,8 @@ def cases():
     out["many_chunks"] = (gz(TEXT * 12), TEXT * 12)
     # hundreds of small members (what a BGZF file looks like to a reader that ignores its size
     # fields): a stretch has to step over member trailers and headers, and every block is a final one
+    zeros = b"\0" * 60_000_000  # 1000:1 -- the parallel decoder must not hold it all as symbols at once
+    out["very_compressible"] = (gz(zeros, 9), zeros)
     out["small_members"] = (b"".join(gz(TEXT[i * 20000:(i + 1) * 20000], 6) for i in range(41)) * 8, TEXT[:820000] * 8)
     return out
 
