@@ -173,6 +173,18 @@ int sk_kernel_for(const sk_batch *batch);
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */
 const char *sk_kernel_name(int which);
 
+/* ---- BGZF block deflate for the -g writer (no counterpart in the reference, whose -g hands the
+ * records to gzprintf, src/trim_single.cpp:418).  text: n_blocks blocks at a stride of 65280 bytes,
+ * block b holding sizes[b] (<= 65280) bytes; out: n_blocks slots of 65536 bytes; out_sizes[b] = the
+ * length of block b's deflate stream in its slot, or 0 when the block does not compress into the
+ * slot (the caller then writes it as a stored block).  The caller frames each stream as a gzip
+ * member with the BGZF size field, CRC-32 and ISIZE.  Host pointers (pinned ones from
+ * sk_bgzf_host_alloc are copied fastest); synchronous; callable from several threads. */
+int sk_bgzf_deflate(int device, const uint8_t *text, const uint32_t *sizes, uint32_t n_blocks, uint8_t *out, uint32_t *out_sizes);
+void *sk_bgzf_host_alloc(size_t bytes);
+void sk_bgzf_host_free(void *p);
+const char *sk_bgzf_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

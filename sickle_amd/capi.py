@@ -16,7 +16,8 @@ QUALTYPES = {"phred": 0, "sanger": 1, "solexa": 2, "illumina": 3}
 EXPORTS = ("sk_quality_constants", "sk_typename", "sk_abi_version", "sk_device_count", "sk_create",
            "sk_destroy", "sk_last_error", "sk_device", "sk_host_alloc", "sk_host_free",
            "sk_scan_device_async", "sk_scan_device_finish", "sk_trim_batch", "sk_submit", "sk_wait",
-           "sk_kernel_for", "sk_kernel_name")
+           "sk_kernel_for", "sk_kernel_name", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
+           "sk_bgzf_last_error")
 
 
 class Params(C.Structure):
@@ -105,6 +106,9 @@ def lib():
         L.sk_kernel_for.argtypes = [C.POINTER(Batch)]
         L.sk_kernel_name.restype = C.c_char_p
         L.sk_kernel_name.argtypes = [C.c_int]
+        L.sk_bgzf_deflate.restype = C.c_int
+        L.sk_bgzf_deflate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.sk_bgzf_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -198,3 +202,36 @@ class Context:
     def scan_device_finish(self, stream=None):
         err = Err()
         self._check(lib().sk_scan_device_finish(self._h, stream, C.byref(err)), err)
+
+
+BGZF_INPUT = 65280   # bytes of text per BGZF block
+BGZF_SLOT = 65536    # bytes of output slot per block
+
+
+def bgzf_deflate(data, device=0):
+    """sk_bgzf_deflate on a bytes object -> the BGZF file image (framing done here, like the
+    writer of the CLI does it).  Tests only."""
+    import struct
+    import zlib
+    n_blocks = max(1, (len(data) + BGZF_INPUT - 1) // BGZF_INPUT)
+    text = np.zeros(n_blocks * BGZF_INPUT, dtype=np.uint8)
+    text[:len(data)] = np.frombuffer(data, dtype=np.uint8)
+    sizes = np.array([min(BGZF_INPUT, len(data) - b * BGZF_INPUT) for b in range(n_blocks)], dtype=np.uint32)
+    out = np.zeros(n_blocks * BGZF_SLOT, dtype=np.uint8)
+    out_sizes = np.zeros(n_blocks, dtype=np.uint32)
+    rc = lib().sk_bgzf_deflate(device, text.ctypes.data, sizes.ctypes.data, n_blocks, out.ctypes.data, out_sizes.ctypes.data)
+    if rc != 0:
+        raise SickleError("sk_bgzf_deflate: %d %s" % (rc, lib().sk_bgzf_last_error().decode()))
+    blob = bytearray()
+    for b in range(n_blocks):
+        piece = data[b * BGZF_INPUT:b * BGZF_INPUT + int(sizes[b])]
+        c = int(out_sizes[b])
+        if c == 0 or c >= len(piece) + 5:
+            n = len(piece)
+            body = bytes([1, n & 0xff, n >> 8, ~n & 0xff, (~n >> 8) & 0xff]) + piece
+        else:
+            body = out[b * BGZF_SLOT:b * BGZF_SLOT + c].tobytes()
+        total = 18 + len(body) + 8
+        blob += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", total - 1) + body
+        blob += struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece))
+    return bytes(blob)
