@@ -175,7 +175,7 @@ const char *sk_kernel_name(int which);
 
 /* ---- BGZF block deflate for the -g writer (no counterpart in the reference, whose -g hands the
  * records to gzprintf, src/trim_single.cpp:418).  text: n_blocks blocks at a stride of 65280 bytes,
- * block b holding sizes[b] (<= 65280) bytes; out: n_blocks slots of 65536 bytes; out_sizes[b] = the
+ * block b holding sizes[b] (<= 65280) bytes (the buffer may end with the last block's bytes); out: n_blocks slots of 65536 bytes; out_sizes[b] = the
  * length of block b's deflate stream in its slot, or 0 when the block does not compress into the
  * slot (the caller then writes it as a stored block).  The caller frames each stream as a gzip
  * member with the BGZF size field, CRC-32 and ISIZE.  Host pointers (pinned ones from

@@ -1,5 +1,6 @@
 #include "trim.h"
 
+#include "Deflate.h"
 #include "FqDeflate.h"
 #include "WorkerPool.h"
 
@@ -35,7 +36,8 @@ bool OutFile::open(const char *path, bool gz)
     pos = 0;
     gzip = gz;
     gz_level = 6; // zlib's default, what the reference's gzopen(path, "w") uses
-    if (const char *e = getenv("SICKLE_GZ_LEVEL")) gz_level = strcmp(e, "fast") == 0 ? -1 : std::max(1, std::min(9, atoi(e)));
+    if (const char *e = getenv("SICKLE_GZ_LEVEL"))
+        gz_level = strcmp(e, "gpu") == 0 ? -2 : strcmp(e, "fast") == 0 ? -1 : std::max(1, std::min(9, atoi(e)));
     struct stat st;
     seekable = fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
     return fd >= 0;
@@ -75,6 +77,54 @@ void OutFile::put(const char *p, size_t n)
 // here, bgzip -@, samtools -- finds the block boundaries without inflating and works on the
 // blocks in parallel.  The blocks are made by FqDeflate.cpp on the worker pool.
 
+int OutFile::gpu_device = 0;
+
+// one part of a batch -> BGZF members, the deflate streams made by sk_bgzf_deflate
+void OutFile::gpu_bgzf(const std::string &text, std::string &out)
+{
+    if (text.empty()) return;
+    const uint32_t n_blocks = (uint32_t)((text.size() + kBgzfInput - 1) / kBgzfInput);
+    std::vector<uint32_t> sizes(n_blocks), csize(n_blocks);
+    for (uint32_t b = 0; b < n_blocks; ++b) sizes[b] = (uint32_t)std::min(kBgzfInput, text.size() - (size_t)b * kBgzfInput);
+    RawBuf slots; // 64 KiB per block, not initialised
+    slots.reserve((size_t)n_blocks * 65536);
+    const int rc = sk_bgzf_deflate(gpu_device, (const uint8_t *)text.data(), sizes.data(), n_blocks, (uint8_t *)slots.data(), csize.data());
+    if (rc != SK_OK) { // no CPU fallback behind the GPU setting
+        error(std::string("sk_bgzf_deflate failed: ") + sk_bgzf_last_error());
+        exit(EXIT_FAILURE);
+    }
+    size_t total = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) total += 26 + (csize[b] && csize[b] < sizes[b] + 5 ? csize[b] : sizes[b] + 5);
+    out.resize(total);
+    size_t at = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const unsigned char *p = (const unsigned char *)text.data() + (size_t)b * kBgzfInput;
+        const uint32_t n = sizes[b];
+        unsigned char *m = (unsigned char *)out.data() + at;
+        memcpy(m, kBgzfEofBlock, 16);
+        size_t clen;
+        if (csize[b] && csize[b] < n + 5) {
+            clen = csize[b];
+            memcpy(m + 18, slots.data() + (size_t)b * 65536, clen);
+        } else { // did not compress: one stored block
+            clen = n + 5;
+            m[18] = 1;
+            m[19] = (unsigned char)(n & 0xff);
+            m[20] = (unsigned char)(n >> 8);
+            m[21] = (unsigned char)(~n & 0xff);
+            m[22] = (unsigned char)((~n >> 8) & 0xff);
+            memcpy(m + 23, p, n);
+        }
+        const uint32_t whole = (uint32_t)(18 + clen + 8), crc = deflate_crc32(p, n);
+        m[16] = (unsigned char)((whole - 1) & 0xff);
+        m[17] = (unsigned char)((whole - 1) >> 8);
+        unsigned char *tail = m + 18 + clen;
+        for (int i = 0; i < 4; ++i) tail[i] = (unsigned char)(crc >> (8 * i));
+        for (int i = 0; i < 4; ++i) tail[4 + i] = (unsigned char)(n >> (8 * i));
+        at += whole;
+    }
+}
+
 void OutFile::write(const std::string &data)
 {
     if (data.empty() || fd < 0) return;
@@ -102,6 +152,14 @@ void OutFile::write_parts(const std::vector<std::string> &parts)
             for (size_t at = 0; at < s.size(); at += kBgzfInput)
                 pieces.push_back({s.data() + at, std::min(kBgzfInput, s.size() - at)});
         if (pieces.empty()) return;
+        if (gz_level == -2) { // the blocks are deflated on the GPU, part by part, and framed here
+            std::vector<std::string> framed(parts.size());
+            WorkerPool::instance().parallel_for(parts.size(), parts.size(), [&](size_t lo, size_t hi, size_t) {
+                for (size_t i = lo; i < hi; ++i) gpu_bgzf(parts[i], framed[i]);
+            });
+            for (const std::string &m : framed) put(m.data(), m.size());
+            return;
+        }
         const size_t groups = std::min(pieces.size(), (size_t)WorkerPool::instance().size() * 4);
         std::vector<std::string> packed(groups);
         WorkerPool::instance().parallel_for(pieces.size(), groups, [&](size_t lo, size_t hi, size_t g) {
@@ -167,6 +225,7 @@ int Abstract_Trimmer::open_device()
         const char *e = getenv("SICKLE_DEVICE");
         device_ids.push_back(e ? atoi(e) : 0);
     }
+    OutFile::gpu_device = device_ids[0];
     ctxs.assign(device_ids.size(), nullptr);
     slots.assign((size_t)n_slots(), Slot());
     device_opener = std::thread([this] {

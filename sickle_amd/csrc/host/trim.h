@@ -39,13 +39,15 @@ public:
     void write_parts(const std::vector<std::string> &parts);
     void close();
     bool is_open() const { return fd >= 0; }
+    static int gpu_device; // SICKLE_GZ_LEVEL=gpu: the device that deflates the blocks
 
 private:
     void put(const char *p, size_t n); // at the current position
+    static void gpu_bgzf(const std::string &text, std::string &out);
     int fd = -1;
     bool seekable = false; // a regular file: positional writes; pipes and devices get plain write(2)
     bool gzip = false;
-    int gz_level = 6;  // SICKLE_GZ_LEVEL=1..9: zlib at that level; =fast (-1): the FASTQ-shaped encoder (FqDeflate)
+    int gz_level = 6;  // SICKLE_GZ_LEVEL=1..9: zlib at that level; =fast (-1): FqDeflate on the host; =gpu (-2): on the GPU
     uint64_t pos = 0;
 };
 

@@ -131,7 +131,9 @@ int sk_bgzf_deflate(int device, const uint8_t *text, const uint32_t *sizes, uint
         SKD_HIP(hipMalloc(&s.d_tok, cap * (SKD_BLOCK_MAX + 8) * sizeof(uint32_t)));
         s.cap_grid = cap;
     }
-    SKD_HIP(hipMemcpyAsync(s.d_text, text, (size_t)n_blocks * SKD_BLOCK_MAX, hipMemcpyHostToDevice, s.stream));
+    // the text ends with its last block: nothing is read past sizes[n_blocks-1] bytes of it
+    const size_t text_bytes = (size_t)(n_blocks - 1) * SKD_BLOCK_MAX + sizes[n_blocks - 1];
+    SKD_HIP(hipMemcpyAsync(s.d_text, text, text_bytes, hipMemcpyHostToDevice, s.stream));
     SKD_HIP(hipMemcpyAsync(s.d_sizes, sizes, (size_t)n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     hipLaunchKernelGGL(sk_bgzf_deflate_kernel, dim3((unsigned)grid), dim3(SKD_LANES), 0, s.stream, s.d_text, s.d_sizes, n_blocks,
                        s.d_out, s.d_tok, s.d_out_sizes);

@@ -63,3 +63,20 @@ def test_multi_device_round_robin_same_output(workdir):
     assert pr.returncode == 0, pr.stderr
     for o, meta in rec["outputs"].items():
         assert cu.md5_file(os.path.join(str(workdir), o)) == meta["md5"], o
+
+
+def test_gzip_output_deflated_on_the_gpu(workdir):
+    """-g with SICKLE_GZ_LEVEL=gpu: the BGZF blocks come from sk_bgzf_deflate; the file inflates to
+    exactly the plain output and equals, byte for byte, what the zlib setting's file inflates to."""
+    import gzip
+    d = str(workdir)
+    big = os.path.join(d, "gpu_gz_src.fastq")
+    open(big, "wb").write(open(os.path.join(cu.INPUTS, "test.fastq"), "rb").read() * 30)
+    outs = {}
+    for tag, extra, env in (("plain", [], None), ("gpu", ["-g"], {"SICKLE_GZ_LEVEL": "gpu"}), ("zlib", ["-g"], None)):
+        o = os.path.join(d, "gpu_gz_%s.out" % tag)
+        pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", big, "-t", "illumina", "-o", o, "-a", "2"] + extra, env=env)
+        assert pr.returncode == 0, pr.stderr
+        outs[tag] = open(o, "rb").read()
+    assert gzip.decompress(outs["gpu"]) == outs["plain"] == gzip.decompress(outs["zlib"])
+    assert len(outs["gpu"]) < 0.6 * len(outs["plain"]) and outs["gpu"][-28:] == outs["zlib"][-28:]  # both end with the BGZF marker block

@@ -282,10 +282,12 @@ def test_gzip_output_is_bgzf_and_reads_back(hostcheck, workdir):
     big = os.path.join(d, "bgzf_src.fastq")
     open(big, "wb").write(open(src, "rb").read() * 40)  # several blocks per worker
     out, plain = os.path.join(d, "bz.fastq.gz"), os.path.join(d, "bz_plain.fastq")
-    fast = os.path.join(d, "bz_fast.fastq.gz")
-    for extra, o, env in ((["-g"], out, None), ([], plain, None), (["-g"], fast, {"SICKLE_GZ_LEVEL": "fast"})):
+    fast, gpu = os.path.join(d, "bz_fast.fastq.gz"), os.path.join(d, "bz_gpu.fastq.gz")
+    for extra, o, env in ((["-g"], out, None), ([], plain, None), (["-g"], fast, {"SICKLE_GZ_LEVEL": "fast"}),
+                          (["-g"], gpu, {"SICKLE_GZ_LEVEL": "gpu"})):  # (the host build runs the GPU encoder's phases on the CPU)
         assert cu.run_cli(hostcheck, workdir, ["se", "-f", big, "-t", "illumina", "-o", o, "-a", "3"] + extra, env=env).returncode == 0
-    assert gzip.decompress(open(fast, "rb").read()) == open(plain, "rb").read() and _walk_bgzf(open(fast, "rb").read())[-1] == 0
+    for alt in (fast, gpu):
+        assert gzip.decompress(open(alt, "rb").read()) == open(plain, "rb").read() and _walk_bgzf(open(alt, "rb").read())[-1] == 0
     blob = open(out, "rb").read()
     sizes = _walk_bgzf(blob)
     assert sizes[-1] == 0 and len(sizes) > 20 and max(sizes) <= 0xff00

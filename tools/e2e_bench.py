@@ -103,6 +103,12 @@ def main():
                 t, m, size = run(NEW, d, "gzout", p1, p2, 1, gzout=True)
                 res["gz_out_s"], res["gz_out_reads_per_s"], res["gz_out_identical"] = t, 2 * n / t, m == m_plain
                 res["gz_out_bytes"] = size
+                for setting in ("gpu", "fast"):
+                    os.environ["SICKLE_GZ_LEVEL"] = setting
+                    run(NEW, d, "gzwarm", p1, p2, 1, gzout=True)
+                    t, m, size = run(NEW, d, "gz_" + setting, p1, p2, 1, gzout=True)
+                    del os.environ["SICKLE_GZ_LEVEL"]
+                    res["gz_out_%s_s" % setting], res["gz_out_%s_identical" % setting], res["gz_out_%s_bytes" % setting] = t, m == m_plain, size
             print(json.dumps(res))
             return
         if gz:  # both tools inflate with zlib, one stream per file
