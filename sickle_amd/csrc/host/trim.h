@@ -43,7 +43,8 @@ public:
 
 private:
     void put(const char *p, size_t n); // at the current position
-    static void gpu_bgzf(const std::string &text, std::string &out);
+    void gpu_bgzf(const std::vector<std::string> &parts);
+    unsigned char *pin_text = nullptr, *pin_out = nullptr; // pinned staging of the GPU deflate
     int fd = -1;
     bool seekable = false; // a regular file: positional writes; pipes and devices get plain write(2)
     bool gzip = false;
