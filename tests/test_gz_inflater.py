@@ -243,3 +243,18 @@ def test_gpu_block_encoder_matches_host_run(inflate_check, tmp_path):
         got = capi.bgzf_deflate(data)
         assert gzip.decompress(got) == data, name
         assert got == want, name
+
+
+@pytest.mark.gpu
+def test_gpu_block_encoder_arguments_and_many_blocks():
+    """sk_bgzf_deflate: nothing to do is not an error, bad arguments are, and a batch of a few
+    thousand blocks (more than one round of the persistent grid: 5 workgroups x 256 CUs) inflates
+    to the text."""
+    from sickle_amd import capi
+    L = capi.lib()
+    assert L.sk_bgzf_deflate(0, None, None, 0, None, None) == 0
+    assert L.sk_bgzf_deflate(0, None, None, 3, None, None) != 0
+    assert L.sk_bgzf_deflate(99, None, None, 0, None, None) != 0
+    data = TEXT * 130  # ~1640 blocks
+    blob = capi.bgzf_deflate(data)
+    assert gzip.decompress(blob) == data and len(blob) < 0.5 * len(data)
