@@ -109,7 +109,7 @@ def cpu_baseline(qual_host, n, stride, length, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed launches before the warm-up steps, to get past the device's clock ramp (0 = none)")
