@@ -285,7 +285,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         Lu = len;
         scan_u = Lu > 0 && Lu >= a.lthr;  // reference trim.cpp:21
         wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
-        three_blocks = MFMA && wu > 33;   // windows wider than 33 reach into a third 32-position block
+        three_blocks = MFMA && STAGE == 0 && wu > 33; // windows wider than 33 reach into a third 32-position block (never in the staged kernels: rows <= 160 bytes)
         if (MFMA) {
             // ---- constants of the matrix path.  This lane supplies row m' = lane&31 of A; the
             // hardware puts row m' into accumulator reg r of lane half hh with
