@@ -20,13 +20,20 @@
  * fails (SK_ENODEV / SK_EHIP) when no gfx950 device is usable.
  *
  * Batch layout (struct-of-arrays, packed by the ingest side):
- *   ragged      : offsets != NULL; read r = bytes [offsets[r], offsets[r+1]) of qual (and seq)
+ *   ragged      : offsets != NULL; read r = bytes [offsets[r], offsets[r+1]) of qual (and seq),
+ *                 offsets ascending.  batch->stride is then a HINT: the longest read of the batch
+ *                 (0 = unknown), which sizes the kernel's LDS tiles (sk_submit / sk_trim_batch see
+ *                 the offsets and work it out themselves).  Tiles of 64 consecutive reads are
+ *                 re-strided on their way into LDS and scanned one lane per read; a tile whose
+ *                 reads are too long for that (and the last tile of the batch) goes to the general
+ *                 kernel.
  *   fixed stride: offsets == NULL; read r = bytes [r*stride, r*stride + len_r) with
- *                 len_r = lengths ? lengths[r] : read_len.  The fast tiled kernel is used
- *                 when stride % 8 == 0 and stride <= SK_TILE_MAX_STRIDE and the base
- *                 pointers are 16-byte aligned; any other fixed-stride batch goes through
- *                 the general kernel.  Fastest when stride/8 is ODD (152, 104, 264 ...): the
- *                 rows then spread over all LDS banks; stride/8 even still works, slower.
+ *                 len_r = lengths ? lengths[r] : read_len.  Fastest: stride % 8 == 0, stride <=
+ *                 SK_TILE_MAX_STRIDE, base pointers 16-byte aligned, stride/8 ODD (152, 104, 264
+ *                 ...: the rows then spread over all LDS banks; stride/8 even still works, slower).
+ *                 Any other stride <= SK_TILE_MAX_STRIDE or alignment (e.g. reads packed back to
+ *                 back, stride == read_len) is re-strided like a ragged batch; longer rows go
+ *                 through the general kernel.
  *   segmented   : tiles != NULL (offsets and lengths NULL).  The caller has grouped the reads
  *                 by length: tile t holds `rows` (<= 64) reads of `read_len` bytes each at
  *                 qual[byte_off + i*stride] (stride % 8 == 0, byte_off % 16 == 0), and slot
@@ -47,7 +54,7 @@
 extern "C" {
 #endif
 
-#define SK_ABI_VERSION 1
+#define SK_ABI_VERSION 2
 
 /* quality_type, reference src/sickle.h:61-66 */
 enum { SK_PHRED = 0, SK_SANGER = 1, SK_SOLEXA = 2, SK_ILLUMINA = 3 };
@@ -97,17 +104,31 @@ typedef struct {
     uint32_t reserved; /* 0 */
 } sk_tile;
 
+/* a run of tiles of a segmented batch that is launched together (optional, see sk_batch) */
+typedef struct {
+    uint32_t first_tile; /* index of the run's first tile */
+    uint32_t n_tiles;
+    uint32_t max_stride; /* the largest tile stride in the run: sizes the LDS buffer of its waves */
+    uint32_t wide;       /* != 0 if any tile of the run has read_len / 10 > 33 */
+} sk_seg_class;
+
 typedef struct {
     const uint8_t *qual;
     const uint8_t *seq;      /* NULL unless trunc_n */
     const uint64_t *offsets; /* n_reads+1 entries, or NULL */
-    uint32_t stride;         /* fixed-stride layout; segmented: the largest tile stride */
+    uint32_t stride;         /* fixed-stride layout; segmented: the largest tile stride; ragged: longest read or 0 */
     uint32_t read_len;       /* fixed-stride layout with lengths == NULL */
     const uint32_t *lengths; /* fixed-stride layout, per-read lengths, or NULL */
     uint64_t n_reads;
     const sk_tile *tiles;      /* segmented layout: n_tiles descriptors, or NULL */
     uint32_t n_tiles;
     const uint32_t *out_index; /* segmented layout: n_reads entries */
+    /* segmented layout, optional: the tile array cut into runs that are launched one after the other,
+     * each with LDS sized for its own widest row (a batch sorted by length then gives its short reads
+     * full occupancy).  HOST memory, also for device-resident batches; NULL = one run (sk_submit /
+     * sk_trim_batch then cut the host tiles themselves).  sk_seg_classes() fills such a table. */
+    const sk_seg_class *classes;
+    uint32_t n_classes;
 } sk_batch;
 
 typedef struct sk_ctx sk_ctx;
@@ -164,9 +185,16 @@ int sk_trim_batch(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, s
 int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *batch, sk_cut *out);
 int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 
+/* Cuts the n_tiles HOST tile descriptors into at most max_classes runs of equal occupancy class (and
+ * of equal need for the wide-window matrix loop), merging runs too short to fill the device.
+ * Returns the number of runs written to out (>= 1 for n_tiles > 0), or 0 when the tiles change class
+ * too often for max_classes runs (pass classes = NULL then). */
+uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
+
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
  * 2 = general (wave per read), 3 = tiled over a segmented batch, 4 = tiled with the tile staged
- * through registers (equal lengths, no sequence buffer, row stride 72..160).  For tests and bench
+ * through registers (equal lengths, no sequence buffer, row stride 72..160), 5 = tiled with rows
+ * re-strided on the way into LDS (packed / misaligned fixed stride, ragged).  For tests and bench
  * labels. */
 int sk_kernel_for(const sk_batch *batch);
 

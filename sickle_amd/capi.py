@@ -16,7 +16,7 @@ QUALTYPES = {"phred": 0, "sanger": 1, "solexa": 2, "illumina": 3}
 EXPORTS = ("sk_quality_constants", "sk_typename", "sk_abi_version", "sk_device_count", "sk_create",
            "sk_destroy", "sk_last_error", "sk_device", "sk_host_alloc", "sk_host_free",
            "sk_scan_device_async", "sk_scan_device_finish", "sk_trim_batch", "sk_submit", "sk_wait",
-           "sk_kernel_for", "sk_kernel_name", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
+           "sk_kernel_for", "sk_kernel_name", "sk_seg_classes", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
            "sk_bgzf_last_error")
 
 
@@ -41,7 +41,19 @@ TILE_DTYPE = np.dtype([("byte_off", "<u8"), ("slot0", "<u4"), ("stride", "<u4"),
 class Batch(C.Structure):
     _fields_ = [("qual", C.c_void_p), ("seq", C.c_void_p), ("offsets", C.c_void_p), ("stride", C.c_uint32),
                 ("read_len", C.c_uint32), ("lengths", C.c_void_p), ("n_reads", C.c_uint64),
-                ("tiles", C.c_void_p), ("n_tiles", C.c_uint32), ("out_index", C.c_void_p)]
+                ("tiles", C.c_void_p), ("n_tiles", C.c_uint32), ("out_index", C.c_void_p),
+                ("classes", C.c_void_p), ("n_classes", C.c_uint32)]
+
+
+class SegClass(C.Structure):
+    _fields_ = [("first_tile", C.c_uint32), ("n_tiles", C.c_uint32), ("max_stride", C.c_uint32), ("wide", C.c_uint32)]
+
+
+def seg_classes(tiles, max_classes=16):
+    """sk_seg_classes on a numpy TILE_DTYPE array -> (ctypes array, count); count 0 = pass no table."""
+    arr = (SegClass * max_classes)()
+    n = lib().sk_seg_classes(tiles.ctypes.data, len(tiles), arr, max_classes)
+    return arr, n
 
 
 class SickleError(RuntimeError):
@@ -106,6 +118,8 @@ def lib():
         L.sk_kernel_for.argtypes = [C.POINTER(Batch)]
         L.sk_kernel_name.restype = C.c_char_p
         L.sk_kernel_name.argtypes = [C.c_int]
+        L.sk_seg_classes.restype = C.c_uint32
+        L.sk_seg_classes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.sk_bgzf_deflate.restype = C.c_int
         L.sk_bgzf_deflate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.sk_bgzf_last_error.restype = C.c_char_p

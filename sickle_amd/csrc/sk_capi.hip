@@ -28,6 +28,7 @@ const int32_t kQualityConstants[4][3] = {
 const char *const kTypeNames[4] = {"Phred", "Sanger", "Solexa", "Illumina"};
 
 constexpr unsigned long long kNoError = ~0ull;
+constexpr uint32_t SK_SEG_MAX_CLASSES = 16;
 
 struct Slot {
     bool busy = false;
@@ -40,6 +41,7 @@ struct Slot {
     uint32_t *d_out_index = nullptr;
     size_t cap_tiles = 0, cap_index = 0;
     sk_cut_dev *d_out = nullptr;
+    std::vector<sk_seg_class> classes;   // segmented batches without a class table: cut here
     unsigned long long *d_err = nullptr; // device error word of this slot
     unsigned long long *h_err = nullptr; // pinned copy
     hipEvent_t copied = nullptr;         // H2D done (copy stream)
@@ -77,6 +79,8 @@ void set_error(sk_ctx *ctx, const char *fmt, ...)
             return SK_EHIP;                                                                    \
         }                                                                                      \
     } while (0)
+
+bool tile_eligible(const sk_batch *b);
 
 int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *a)
 {
@@ -133,7 +137,32 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->n_tiles = b->tiles ? b->n_tiles : 0;
     static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
     a->tile_order = order;
+    a->buf_bytes = 0;
+    a->first_group = 0;
     return SK_OK;
+}
+
+// LDS bytes per wave for the tiles of a ragged batch whose reads are at most `max_len` bytes
+// (0 = unknown): 64 reads + what a lane may read past its row, so that uniform 150 bp gets 10 KiB
+// (16 waves per CU); tiles that do not fit go to the general kernel.
+uint32_t rag_buf_bytes(uint64_t max_len)
+{
+    if (max_len == 0) return SK_RAG_BUF_DEFAULT;
+    const uint64_t pitch = 16 * (((max_len + 15) >> 4) | 1); // == rag_pitch() of the kernels
+    uint64_t need = 64 * pitch + SK_TILE_SLACK;
+    if (need < 4096) need = 4096;
+    if (need > SK_RAG_BUF_MAX) need = SK_RAG_BUF_MAX;
+    return (uint32_t)need;
+}
+
+// which path a batch takes: 3 segmented, 1 tiled (aligned rows), 5 tiled (rows at any address),
+// 2 general kernel only
+int path_of(const sk_batch *b)
+{
+    if (b->tiles) return 3;
+    if (tile_eligible(b)) return 1;
+    if (!b->offsets && !b->lengths) return (b->stride <= SK_TILE_MAX_STRIDE) ? 5 : 2;
+    return 5; // ragged: tiles that fit a wave's LDS buffer by the tile kernel, the others by the general one
 }
 
 bool tile_eligible(const sk_batch *b)
@@ -150,13 +179,25 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
 {
     if (a->n_reads == 0) return SK_OK;
     const uint8_t *seq = a->truncn ? b->seq : nullptr;
-    if (b->tiles)
+    const int path = path_of(b);
+    if (path == 3) {
         SK_HIP(ctx, sk_launch_seg(b->qual, seq, reinterpret_cast<const sk_tile_dev *>(b->tiles), b->out_index, out, d_err, a,
-                                  ctx->cu_count, stream));
-    else if (tile_eligible(b))
+                                  b->classes, b->n_classes, ctx->cu_count, stream));
+    } else if (path == 1) {
         SK_HIP(ctx, sk_launch_tile(b->qual, seq, b->lengths, out, d_err, a, ctx->cu_count, stream));
-    else
+    } else if (path == 5) {
+        sk_scan_args ar = *a;
+        const bool ragged = b->offsets || b->lengths;
+        // b->stride of an `offsets` batch is the caller's hint of the longest read (0 = unknown); with
+        // stride + lengths it bounds the reads; packed uniform batches: the read length is known
+        ar.buf_bytes = rag_buf_bytes(ragged ? b->stride : b->read_len);
+        SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
+        // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
+        // packed uniform batch)
+        if (ragged) SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
+    } else {
         SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, a, ctx->cu_count, stream));
+    }
     return SK_OK;
 }
 
@@ -345,11 +386,57 @@ int sk_kernel_for(const sk_batch *batch)
 {
     if (!batch) return 0;
     if (batch->tiles) return 3;
-    if (!tile_eligible(batch)) return 2;
+    if (!tile_eligible(batch)) return path_of(batch);
     // uniform batches without a sequence buffer (no -n) and rows of 72..160 bytes: the tile comes in
     // through the wave's registers instead of LDS-DMA
     if (!batch->lengths && !batch->seq && sk_tile_is_staged(batch->stride, batch->read_len, 0)) return 4;
     return 1;
+}
+
+uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes)
+{
+    if (!tiles || !out || n_tiles == 0 || max_classes == 0) return 0;
+    // occupancy class of a tile = single-wave workgroups per CU its LDS buffer allows (16 down to 4)
+    auto per_cu = [](uint32_t stride) {
+        const uint32_t lds = 64u * stride + SK_TILE_SLACK;
+        const uint32_t n = lds ? SK_LDS_PER_CU / lds : 16u;
+        return n > 16u ? 16u : n;
+    };
+    auto wide = [](const sk_tile &t) -> uint32_t { return (uint32_t)(t.read_len / 10) > 33u; };
+    // pass 1: maximal runs of equal (occupancy, wide)
+    std::vector<sk_seg_class> runs;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t pc = per_cu(tiles[t].stride), w = wide(tiles[t]);
+        if (!runs.empty() && per_cu(runs.back().max_stride) == pc && runs.back().wide == w) {
+            runs.back().n_tiles++;
+            if (tiles[t].stride > runs.back().max_stride) runs.back().max_stride = tiles[t].stride;
+        } else {
+            if (runs.size() >= 4096) return 0; // not a sorted batch
+            runs.push_back(sk_seg_class{t, 1u, tiles[t].stride, w});
+        }
+    }
+    // pass 2: runs are gathered into a class until it can fill the device a few times over; then the
+    // next run of a different kind opens a new class (a class takes the widest stride and the wide
+    // loop of its runs); a short last class joins the one before it
+    static const uint32_t min_tiles = [] { const char *e = getenv("SK_SEG_MIN_TILES"); return e ? (uint32_t)atoi(e) : 8192u; }();
+    std::vector<sk_seg_class> merged;
+    auto join = [](sk_seg_class &m, const sk_seg_class &r) {
+        m.n_tiles += r.n_tiles;
+        if (r.max_stride > m.max_stride) m.max_stride = r.max_stride;
+        m.wide |= r.wide;
+    };
+    for (const sk_seg_class &r : runs) {
+        if (!merged.empty() && merged.back().n_tiles < min_tiles) join(merged.back(), r);
+        else merged.push_back(r);
+    }
+    if (merged.size() > 1 && merged.back().n_tiles < min_tiles) {
+        const sk_seg_class last = merged.back();
+        merged.pop_back();
+        join(merged.back(), last);
+    }
+    if (merged.size() > max_classes) return 0;
+    for (size_t i = 0; i < merged.size(); ++i) out[i] = merged[i];
+    return (uint32_t)merged.size();
 }
 
 const char *sk_kernel_name(int which)
@@ -359,6 +446,7 @@ const char *sk_kernel_name(int which)
     case 2: return "sk_scan_wave_kernel";
     case 3: return "sk_scan_tile_kernel";
     case 4: return "sk_scan_tile_staged_kernel";
+    case 5: return "sk_scan_tile_any_kernel";
     default: return "";
     }
 }
@@ -404,6 +492,20 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
                 return SK_EINVAL;
             }
     }
+    uint64_t rag_max_len = 0;
+    if (batch->offsets) {
+        // host offsets are checked here (ascending, reads within SK_MAX_READ_LEN: the error word keeps
+        // 24 bits of position) and give the exact longest read, which sizes the tile kernel's buffers
+        for (size_t r = 0; r < n; ++r) {
+            const uint64_t o = batch->offsets[r], e = batch->offsets[r + 1];
+            if (e < o || e - o > SK_MAX_READ_LEN) {
+                set_error(ctx, "offsets[%zu..%zu] = %llu, %llu: not ascending, or a read longer than %u", r, r + 1,
+                          (unsigned long long)o, (unsigned long long)e, SK_MAX_READ_LEN);
+                return SK_EINVAL;
+            }
+            if (e - o > rag_max_len) rag_max_len = e - o;
+        }
+    }
     rc = grow_slot(ctx, s, bytes, n, a.truncn != 0, batch->offsets != nullptr, batch->lengths != nullptr);
     if (rc != SK_OK) return rc;
     if (batch->tiles) {
@@ -445,6 +547,10 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
             SK_HIP(ctx, hipMalloc(&s.d_out_index, cap * sizeof(uint32_t)));
             s.cap_index = cap;
         }
+        if (!batch->classes) {
+            s.classes.resize(SK_SEG_MAX_CLASSES);
+            s.classes.resize(sk_seg_classes(batch->tiles, batch->n_tiles, s.classes.data(), SK_SEG_MAX_CLASSES));
+        }
         SK_HIP(ctx, hipMemcpyAsync(s.d_tiles, batch->tiles, batch->n_tiles * sizeof(sk_tile), hipMemcpyHostToDevice, ctx->copy));
         SK_HIP(ctx, hipMemcpyAsync(s.d_out_index, batch->out_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy));
     }
@@ -465,9 +571,14 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
     dev.qual = s.d_qual;
     dev.seq = a.truncn ? s.d_seq : nullptr;
     dev.offsets = batch->offsets ? s.d_offsets : nullptr;
+    if (batch->offsets) dev.stride = (uint32_t)rag_max_len;
     dev.lengths = (!batch->offsets && batch->lengths) ? s.d_lengths : nullptr;
     dev.tiles = batch->tiles ? reinterpret_cast<const sk_tile *>(s.d_tiles) : nullptr;
     dev.out_index = batch->tiles ? s.d_out_index : nullptr;
+    if (batch->tiles && !batch->classes && !s.classes.empty()) {
+        dev.classes = s.classes.data();
+        dev.n_classes = (uint32_t)s.classes.size();
+    }
     rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute);
     if (rc != SK_OK) return rc;
     if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));

@@ -233,13 +233,107 @@ typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 // buffer per wave without costing LDS.
 typedef unsigned sk_v4u __attribute__((ext_vector_type(4)));
 
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, bool SEG, int STAGE>
+namespace {
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// row pitch of the LDS image the re-striding loader builds for reads of up to `len` bytes.  The loader
+// moves 16 bytes per lane, so a multiple of 16; an ODD number of 16-byte units spreads the rows'
+// 8-byte reads over all banks two lanes to a bank pair (with 16-byte granules that is the best there
+// is; 4-byte granules give the conflict-free pitch of the strided layouts but cost four times the DMA
+// instructions, which measured slower: 3.2 against TB/s on packed 150 bp)
+__device__ __forceinline__ uint32_t rag_pitch(uint32_t len) { return 16u * (((len + 15u) >> 4) | 1u); }
+
+// One tile = reads [64t, 64t+64) of a batch whose rows start at any byte address (`offsets`, or a
+// fixed stride that is not a multiple of 8, with or without `lengths`), as its lanes see it
+struct sk_rag_tile {
+    uint64_t start;  // wave-uniform: byte offset of the tile's first read
+    uint32_t span;   // wave-uniform: bytes from there to the end of its last read (saturated)
+    uint32_t rowoff; // per lane: this lane's read starts at start + rowoff
+    int len;         // per lane: its length (0 for lanes past the end of the batch)
+    int lmax;        // wave-uniform: the longest of them
+};
+
+__device__ __forceinline__ sk_rag_tile rag_probe(uint64_t t, int lane, const uint64_t *__restrict__ offsets,
+                                                 const uint32_t *__restrict__ lengths, const sk_scan_args &a)
+{
+    const uint64_t r = (t << 6) + lane;
+    const uint64_t rc = min(r, a.n_reads - 1);
+    uint64_t o, e;
+    if (offsets) {
+        o = offsets[rc];
+        e = offsets[rc + 1];
+    } else {
+        o = rc * a.stride;
+        e = o + (lengths ? min(lengths[rc], a.stride) : a.read_len);
+    }
+    const int last = (int)min((uint64_t)63, a.n_reads - 1 - (t << 6));
+    sk_rag_tile g;
+    g.start = readlane_u64(o, 0);
+    const uint64_t end = readlane_u64(e, last);
+    const uint64_t span = end >= g.start ? end - g.start : ~0ull;
+    g.span = (uint32_t)min(span, (uint64_t)0xffffffffu);
+    // offsets that do not ascend give a read no bytes rather than bytes outside its tile
+    const bool ok = r < a.n_reads && o >= g.start && e >= o && e <= end;
+    g.rowoff = ok ? (uint32_t)(o - g.start) : 0u;
+    g.len = ok ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
+    g.lmax = __builtin_amdgcn_readfirstlane(wave_max(g.len));
+    return g;
+}
+
+// Is the tile sk_scan_tile_any_kernel's?  Its re-strided image (64 rows at rag_pitch(lmax)) must fit
+// the wave's LDS buffer.  sk_scan_wave_kernel asks the same question and takes the other tiles.
+__device__ __forceinline__ bool rag_tile_fits(const sk_rag_tile &g, uint32_t buf_bytes)
+{
+    return g.lmax <= SK_RAG_MAX_LEN && 64u * rag_pitch((uint32_t)g.lmax) + SK_TILE_SLACK <= buf_bytes;
+}
+
+// end of the batch's bytes (exclusive), for the test above
+__device__ __forceinline__ uint64_t rag_batch_end(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
+                                                  const sk_scan_args &a)
+{
+    if (offsets) return offsets[a.n_reads];
+    return (a.n_reads - 1) * a.stride + (lengths ? min(lengths[a.n_reads - 1], a.stride) : a.read_len);
+}
+
+// what a wave needs to know about one tile
+struct sk_tile_view {
+    uint64_t off;    // wave-uniform: byte offset of the tile (of its first read) in qual / seq
+    uint32_t bytes;  // wave-uniform: bytes of the tile in global memory
+    uint32_t ts;     // wave-uniform: row pitch of its LDS image
+    uint32_t rows;   // wave-uniform: reads in it
+    int len;         // read length: one value when UNIFORM, per lane otherwise (0 past the end)
+    uint64_t r;      // per lane: where this lane's cut goes in out[]
+    uint32_t rowoff; // ragged: per lane, where the lane's read starts, relative to off
+    bool take;       // rows at any address: false = left to sk_scan_wave_kernel
+};
+
+} // namespace
+
+// RAG (rows at any byte address: packed fixed-stride batches whose stride is not a multiple of 8 or
+// whose base is not 16-byte aligned, and ragged `offsets` batches): the tile is RE-STRIDED on its way
+// into LDS.  LDS-DMA takes a per-lane global address, so lane i of piece p fetches the 4 bytes that
+// belong at dword 64p+i of an image with rows at pitch rag_pitch(longest read) -- (row, dword) =
+// divmod(64p+i, pitch/4), source = that row's start + 4*dword, at whatever alignment -- and the
+// image the scan sees is the aligned, bank-friendly one of the strided layouts.  Measured
+// (tools/probes/restride_probe.hip): the re-striding DMA streams at the rate of the plain one
+// (6.4 TB/s), whereas reading unaligned rows out of LDS costs 8x per ds_read.  Uniform lengths keep
+// the matrix path; per-lane lengths walk the vector-ALU path.  A tile whose image does not fit the
+// wave's buffer (long reads) is left to sk_scan_wave_kernel.
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                   const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                   unsigned long long *errword, const sk_scan_args &a, const sk_tile_dev *__restrict__ tiles,
-                  const uint32_t *__restrict__ out_index)
+                  const uint32_t *__restrict__ out_index, const uint64_t *__restrict__ offsets)
 {
+    static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
+    static_assert(!RAG || UNIFORM || !MFMA, "ragged batches walk the vector-ALU path");
     static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
     static_assert(STAGE == 0 || (UNIFORM && !HAS_SEQ && NBUF == 1 && !SEG), "register staging: uniform batches, one buffer");
     static_assert(!SEG || (UNIFORM && MFMA && NBUF == 1), "segmented batches run the uniform matrix path, one buffer");
@@ -255,7 +349,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int waves_per_block = blockDim.x >> 6;
     const uint32_t stride = a.stride; // SEG: the largest row stride of the batch (sizes the LDS buffers)
-    const uint32_t buf_bytes = 64u * stride + SK_TILE_SLACK;
+    const uint32_t buf_bytes = (RAG || SEG) ? a.buf_bytes : 64u * stride + SK_TILE_SLACK;
     uint8_t *buf0 = lds + (size_t)wave * LDS_BUFS * buf_bytes;
     uint8_t *buf1 = LDS_BUFS > 1 ? buf0 + buf_bytes : buf0;
 
@@ -285,25 +379,33 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         Lu = len;
         scan_u = Lu > 0 && Lu >= a.lthr;  // reference trim.cpp:21
         wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
-        three_blocks = MFMA && STAGE == 0 && wu > 33; // windows wider than 33 reach into a third 32-position block (never in the staged kernels: rows <= 160 bytes)
+        // windows wider than 33 reach into a third 32-position block (never in the staged kernels: rows
+        // <= 160 bytes).  Segmented launches fix it at compile time (SEG = 2: every tile of the launch
+        // has w <= 33; SEG = 3: three blocks for every tile, right for any w <= 65): one MFMA loop
+        // instead of two in the kernel, fewer registers
+        three_blocks = MFMA && STAGE == 0 && (SEG == 2 ? false : SEG == 3 ? true : wu > 33);
         if (MFMA) {
             // ---- constants of the matrix path.  This lane supplies row m' = lane&31 of A; the
             // hardware puts row m' into accumulator reg r of lane half hh with
             // m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be window 16*hh + r
-            const int mp = lane & 31;
+            int mp = lane & 31;
+            // segmented batches call this inside the tile loop: without the barrier the compiler hoists
+            // the 48 per-byte position constants out of the loop and pins a register to each
+            if (SEG) asm volatile("" : "+v"(mp));
             const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
             const int win = 16 * hh + r;
-            union { sk_v4i v; int8_t b[16]; } f0, f1, f2;
+            // band bytes of positions p .. p+3 (relative to 32*b): 1 where win <= position < win + wu
+            auto ones_below = [](int n) -> uint32_t { // 0x01 in the bytes j < n of a dword
+                return n >= 4 ? 0x01010101u : (n <= 0 ? 0u : 0x01010101u & ((1u << (8 * n)) - 1u));
+            };
+            auto band4 = [&](int p) -> int { return (int)(ones_below(win + wu - p) & ~ones_below(win - p)); };
+            const int k0 = (lane >> 5) * 16; // the first position (relative to 32*b) this lane's bytes multiply
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int k = 16 * half + t; // the position (relative to 32*b) this byte multiplies
-                f0.b[t] = (int8_t)((win <= k && k < win + wu) ? 1 : 0);
-                f1.b[t] = (int8_t)((win <= k + 32 && k + 32 < win + wu) ? 1 : 0);
-                f2.b[t] = (int8_t)((win <= k + 64 && k + 64 < win + wu) ? 1 : 0);
+            for (int j = 0; j < 4; ++j) {
+                bandA0[j] = band4(k0 + 4 * j);
+                bandA1[j] = band4(k0 + 4 * j + 32);
+                bandA2[j] = band4(k0 + 4 * j + 64);
             }
-            bandA0 = f0.v;
-            bandA1 = f1.v;
-            bandA2 = f2.v;
             const int T = a.craw * wu;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -317,11 +419,95 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     };
     if (!SEG) set_length((int)a.read_len);
 
-    auto tile_bytes_of = [&](uint64_t t) -> uint32_t {
-        if (SEG) return (uint32_t)tiles[t].rows * tiles[t].stride;
-        return (uint32_t)min((uint64_t)64, a.n_reads - (t << 6)) * stride;
+    const uint64_t batch_end = RAG ? rag_batch_end(offsets, lengths, a) : 0;
+    auto probe = [&](uint64_t tt) -> sk_tile_view {
+        sk_tile_view v;
+        v.take = true;
+        v.rowoff = 0;
+        if (SEG) {
+            const sk_tile_dev d = tiles[tt];
+            v.off = d.byte_off;
+            v.ts = d.stride;
+            v.rows = d.rows;
+            v.bytes = v.rows * v.ts;
+            v.len = (int)d.read_len;
+            v.r = d.slot0; // probe_index() turns it into this lane's slot of out[]
+        } else if (RAG && UNIFORM) {
+            v.off = (tt << 6) * stride;
+            v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
+            v.ts = rag_pitch(a.read_len);
+            v.bytes = (v.rows - 1u) * stride + a.read_len;
+            v.len = (int)a.read_len;
+            v.r = (tt << 6) + lane;
+        } else if (RAG) {
+            const sk_rag_tile g = rag_probe(tt, lane, offsets, lengths, a);
+            v.off = g.start;
+            v.bytes = g.span;
+            v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
+            v.ts = rag_pitch((uint32_t)g.lmax);
+            v.len = g.len;
+            v.rowoff = g.rowoff;
+            v.r = (tt << 6) + lane;
+            v.take = rag_tile_fits(g, buf_bytes);
+        } else {
+            v.off = (tt << 6) * stride;
+            v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
+            v.ts = stride;
+            v.bytes = v.rows * stride;
+            v.r = (tt << 6) + lane;
+            v.len = UNIFORM ? (int)a.read_len : (v.r < a.n_reads ? (int)min(lengths[v.r], stride) : 0);
+        }
+        return v;
     };
-    auto tile_off_of = [&](uint64_t t) -> uint64_t { return SEG ? tiles[t].byte_off : (t << 6) * stride; };
+
+    // segmented batches scatter their cuts back to the caller's read order.  The descriptor is a scalar
+    // load (not counted by vmcnt: it can be issued before the wait for the tile); the index is a vector
+    // load that needs the descriptor, issued after that wait, when the descriptor has long arrived
+    auto probe_index = [&](sk_tile_view &v) {
+        v.r = (uint64_t)out_index[(uint32_t)v.r + min((uint32_t)lane, v.rows - 1u)];
+    };
+
+    // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, pitch/16) comes
+    // from the row's start + 16c.  Chunks beyond a row's end fetch what follows it in the batch (nobody
+    // reads them); the clamp keeps those inside the tile (a row's last chunk may still reach up to 15
+    // bytes past it).
+    auto rag_dma = [&](const uint8_t *base, uint8_t *dst, const sk_tile_view &v) {
+        const uint32_t cpr = v.ts >> 4; // 16-byte chunks per image row == pieces per tile
+        const uint32_t qd = 64u / cpr, rd = 64u % cpr;
+        uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
+        const uint8_t *src = base + v.off;
+        const uint32_t lim = (v.bytes ? v.bytes : 1u) - 1u;
+        for (uint32_t p = 0; p < cpr; ++p) {
+            uint32_t ro;
+            if (UNIFORM) ro = rr * stride;
+            else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
+            const uint32_t so = min(ro + 16u * cc, lim);
+            // a chunk may reach up to 15 bytes past its tile: harmless inside the batch, but the last
+            // chunks of the batch's last tile(s) must not leave the caller's buffer -- those few lanes
+            // copy their bytes one by one instead
+            const bool inside = v.off + so + 16u <= batch_end;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inside) == 0, 1)) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + p * 1024u), 16, 0, SK_DMA_AUX);
+            } else {
+                if (inside) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + p * 1024u), 16, 0, SK_DMA_AUX);
+                } else {
+                    for (uint32_t j = 0; j < 16u && v.off + so + j < batch_end; ++j)
+                        dst[p * 1024u + (uint32_t)lane * 16u + j] = src[so + j];
+                }
+            }
+            cc += rd;
+            rr += qd;
+            if (cc >= cpr) {
+                cc -= cpr;
+                ++rr;
+            }
+        }
+    };
+    auto load_tile = [&](const uint8_t *base, uint8_t *dst, const sk_tile_view &v) {
+        if (RAG) rag_dma(base, dst, v);
+        else tile_to_lds(base + v.off, dst, v.bytes, lane);
+    };
 
     // register stage: piece p of a FULL tile (64 rows; 64*stride bytes, a multiple of 512) is the
     // 16 bytes per lane at p KiB; STAGE = the number of pieces, the last one may be a half (its
@@ -333,58 +519,44 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const uint32_t off = (uint32_t)p * 1024u + (uint32_t)lane * 16u;
         return p == STAGE - 1 ? min(off, full_bytes - 16u) : off;
     };
-    auto tile_is_full = [&](uint64_t tt) -> bool { return ((tt + 1) << 6) <= a.n_reads; };
 
     uint64_t t = wave_global;
     if (t >= n_tiles) return;
 
     // prologue: Q(t) [and S(t)] in flight
-    uint32_t cur_bytes = tile_bytes_of(t);
-    bool cur_staged = STAGE && tile_is_full(t);
+    sk_tile_view cur = probe(t), nxt = cur;
+    if (SEG) probe_index(cur);
+    bool cur_staged = STAGE && cur.rows == 64u;
     if (cur_staged) {
 #pragma unroll
         for (int p = 0; p < STAGE; ++p)
-            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + tile_off_of(t) + stage_off(p)));
-    } else {
-        tile_to_lds(qual + tile_off_of(t), buf0, cur_bytes, lane);
+            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + cur.off + stage_off(p)));
+    } else if (cur.take) {
+        load_tile(qual, buf0, cur);
     }
-    if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + tile_off_of(t), buf1, cur_bytes, lane);
-    int len_next = 0;
-    if (!UNIFORM) {
-        const uint64_t r = (t << 6) + lane;
-        len_next = r < a.n_reads ? (int)min(lengths[r], stride) : 0;
-    }
+    if (HAS_SEQ && !SEQ_SHARES) tile_to_lds(seq + cur.off, buf1, cur.bytes, lane);
     int parity = 0; // NBUF == 2: which buffer holds Q(t)
+    // the next tile's view is taken AFTER this tile has landed wherever taking it loads something
+    // (descriptor and out_index of a segmented batch, offsets / lengths): the wait for the tile is a
+    // vmcnt(0), and a load issued just before it would put its whole latency on every tile
+    constexpr bool PROBE_EARLY = NBUF == 2 || STAGE != 0 || ABLATE != 0 || SEG != 0;
 
     for (; t < n_tiles; t += wave_count) {
-        const uint64_t r0 = t << 6;
-        uint32_t ts = stride; // this tile's row stride
-        uint32_t seg_rows = 64;
-        if (SEG) {
-            const sk_tile_dev d = tiles[t];
-            ts = d.stride;
-            seg_rows = d.rows;
-            if ((int)d.read_len != Lu) set_length((int)d.read_len);
-        }
-        // where this lane's cut goes: segmented batches scatter back to the caller's read order
-        const uint64_t r = SEG ? (uint64_t)out_index[tiles[t].slot0 + min((uint32_t)lane, seg_rows - 1u)] : r0 + lane;
         const uint64_t tn = t + wave_count;
         const bool more = tn < n_tiles;
-        const uint32_t next_bytes = more ? tile_bytes_of(tn) : 0u;
-        const int next_pieces = more ? tile_pieces(next_bytes) : 0;
+        if (PROBE_EARLY && more) nxt = probe(tn);
+        const uint32_t ts = cur.ts;  // this tile's row pitch in LDS
+        const uint64_t r = cur.r;
+        const uint32_t cur_bytes = cur.bytes;
+        if (SEG && cur.len != Lu) set_length(cur.len);
+        const uint32_t next_bytes = (PROBE_EARLY && more) ? nxt.bytes : 0u;
+        const int next_pieces = (PROBE_EARLY && more) ? tile_pieces(next_bytes) : 0;
         const uint8_t *tile;
 
-        const bool active = SEG ? (uint32_t)lane < seg_rows : r < a.n_reads;
-        int Lv = 0; // mixed lengths: this lane's length
-        if (!UNIFORM) {
-            if (active) Lv = len_next;
-            if (more) { // next tile's lengths: an ordinary load, issued ahead of the DMA
-                const uint64_t rn = (tn << 6) + lane;
-                len_next = rn < a.n_reads ? (int)min(lengths[rn], stride) : 0;
-            }
-        }
+        const bool active = (uint32_t)lane < cur.rows;
+        const int Lv = UNIFORM ? 0 : cur.len; // mixed lengths: this lane's length (0 past the end of the batch)
 
-        if (SEQ_SHARES) {
+        if (SEQ_SHARES || RAG) {
             tile = buf0;
             wait_vmcnt(0); // Q(t)
         } else if (HAS_SEQ) {
@@ -393,12 +565,12 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             wait_vmcnt(tile_pieces(cur_bytes));
         } else if (STAGE) {
             tile = buf0;
-            const bool next_staged = more && tile_is_full(tn) && ABLATE != 2;
+            const bool next_staged = more && nxt.rows == 64u && ABLATE != 2;
             if (cur_staged && (ABLATE != 2 || t == wave_global)) {
                 // piece by piece: into the LDS buffer, and the register is reloaded at once with the
                 // same piece of the next tile (of the first KiB of this tile again if there is no full
                 // next tile: loads nobody uses keep the code free of branches and its wait counts exact)
-                const uint8_t *nsrc = qual + tile_off_of(next_staged ? tn : t);
+                const uint8_t *nsrc = qual + (next_staged ? nxt.off : cur.off);
                 const uint32_t keep = next_staged ? ~0u : 1023u; // no next tile: every piece re-reads the first KiB
 #pragma unroll
                 for (int p = 0; p < STAGE; ++p) {
@@ -416,17 +588,24 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         } else {
             tile = parity ? buf1 : buf0;
             uint8_t *other = parity ? buf0 : buf1;
-            if (more) tile_to_lds(qual + tile_off_of(tn), other, next_bytes, lane);
+            if (more) tile_to_lds(qual + nxt.off, other, next_bytes, lane);
             wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
             parity ^= 1;
+        }
+        if (!PROBE_EARLY && more) nxt = probe(tn);
+        if (SEG && more) probe_index(nxt);
+        if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_wave_kernel's
+            if (more && nxt.take) load_tile(qual, buf0, nxt);
+            cur = nxt;
+            continue;
         }
         const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * ts);
         if (ABLATE == 1) {
             const sk_cut_dev dummy{(int)row[0], (int)row[1]};
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (NBUF == 1 && more && (!STAGE || !cur_staged)) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
+            if (NBUF == 1 && more && (!STAGE || !cur_staged)) tile_to_lds(qual + nxt.off, buf0, next_bytes, lane);
             if (active) out[r] = dummy;
-            cur_bytes = next_bytes;
+            cur = nxt;
             continue;
         }
 
@@ -531,7 +710,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 const sk_v2u s = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
                 step32((s[0] << 16) | s[1], base);
             };
-            if (!three_blocks) { // w <= 33: positions base .. base+63, two trips per turn so that
+            if (SEG == 2 || (SEG != 3 && !three_blocks)) { // w <= 33: positions base .. base+63, two trips per turn so that
                                  // the fragment registers alternate instead of being copied
                 sk_v4i qa0 = load_frag(frag0), qa1 = load_frag(frag1);
                 for (int base = 0; base < nwinmax; base += 64) {
@@ -655,11 +834,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (SEQ_SHARES) {
                 // the quality scan is over: the same buffer now takes the sequence tile of these reads
-                tile_to_lds(seq + tile_off_of(t), buf0, cur_bytes, lane);
+                load_tile(seq, buf0, cur);
                 wait_vmcnt(0);
             } else {
                 // buf0 is free now: start Q(t+1), then retire S(t)
-                if (more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
+                if (more) tile_to_lds(qual + nxt.off, buf0, next_bytes, lane);
                 wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
             }
             const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)lane * ts);
@@ -698,15 +877,15 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) {
-                if (SEQ_SHARES) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane); // Q(t+1)
-                else tile_to_lds(seq + tile_off_of(tn), buf1, next_bytes, lane);             // S(t+1)
+                if (SEQ_SHARES) { if (nxt.take) load_tile(qual, buf0, nxt); }   // Q(t+1)
+                else tile_to_lds(seq + nxt.off, buf1, next_bytes, lane);      // S(t+1)
             }
         } else if (NBUF == 1 && ABLATE != 2 && (!STAGE || (more && !cur_staged))) {
             // single buffer: every LDS read of this tile is done, refill it now -- the cut store
             // below and the other waves of the CU cover the DMA latency.  (Staged kernel: only the
             // ragged last tile of the batch takes this way.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) tile_to_lds(qual + tile_off_of(tn), buf0, next_bytes, lane);
+            if (more && nxt.take) load_tile(qual, buf0, nxt);
         }
 #if SK_TAIL_PRIO
         __builtin_amdgcn_s_setprio(0);
@@ -721,18 +900,28 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         // this trip's LDS reads are complete (their results were consumed) before the next
         // trip may overwrite the buffer they came from
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cur_bytes = next_bytes;
+        cur = nxt;
     }
 }
 
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0, bool SEG = false>
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA = false, int NBUF = 2, int ABLATE = 0, int SEG = 0>
 __global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                     unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
                     const uint32_t *__restrict__ out_index = nullptr)
 {
-    sk_scan_tile_body<UNIFORM, HAS_SEQ, MFMA, NBUF, ABLATE, SEG, 0>(qual, seq, lengths, out, errword, a, tiles, out_index);
+    sk_scan_tile_body<UNIFORM, HAS_SEQ, MFMA, NBUF, ABLATE, SEG, 0, false>(qual, seq, lengths, out, errword, a, tiles, out_index, nullptr);
+}
+
+// rows at any byte address (RAG): packed uniform batches (matrix path when MFMA) and ragged ones
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA>
+__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
+sk_scan_tile_any_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                        const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
+                        sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
+{
+    sk_scan_tile_body<UNIFORM, HAS_SEQ, MFMA, 1, 0, false, 0, true>(qual, seq, lengths, out, errword, a, nullptr, nullptr, offsets);
 }
 
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
@@ -744,7 +933,7 @@ sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
                            unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
                            const uint32_t *__restrict__ out_index = nullptr)
 {
-    sk_scan_tile_body<true, false, true, 1, ABLATE, false, STAGE>(qual, seq, lengths, out, errword, a, tiles, out_index);
+    sk_scan_tile_body<true, false, true, 1, ABLATE, false, STAGE, false>(qual, seq, lengths, out, errword, a, tiles, out_index, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -759,13 +948,19 @@ sk_scan_wave_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * SK_WAVE_THREADS + threadIdx.x) >> 6;
     const uint64_t wave_count = ((uint64_t)gridDim.x * SK_WAVE_THREADS) >> 6;
+    const uint64_t n_groups = (a.n_reads + 63) >> 6;
+    // a.buf_bytes != 0: only the 64-read tiles sk_scan_tile_any_kernel left (same test as there)
 
-    for (uint64_t r = wave_global; r < a.n_reads; r += wave_count) {
+    for (uint64_t grp = a.first_group + wave_global; grp < n_groups; grp += wave_count) {
+      if (a.buf_bytes && rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes)) continue;
+      const uint64_t r_end = min(a.n_reads, (grp + 1) << 6);
+      for (uint64_t r = grp << 6; r < r_end; ++r) {
         uint64_t off;
         int L;
         if (offsets) {
             off = offsets[r];
-            L = (int)(offsets[r + 1] - off);
+            const uint64_t end = offsets[r + 1];
+            L = end >= off ? (int)min(end - off, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
         } else {
             off = r * a.stride;
             L = lengths ? (int)lengths[r] : (int)a.read_len;
@@ -851,6 +1046,7 @@ sk_scan_wave_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             }
         }
         if (lane == 0) out[r] = sk_cut_dev{five, three};
+      }
     }
 }
 
@@ -975,26 +1171,82 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const uint8_t *qual, const uint8_t *seq, const sk_tile_dev *tiles,
                                     const uint32_t *out_index, sk_cut_dev *out, unsigned long long *errword,
+                                    const sk_scan_args *a, const sk_seg_class *classes, uint32_t n_classes,
+                                    int cu_count, hipStream_t stream)
+{
+    // One launch per class of tiles (a run of the tile array): the LDS buffer of a wave is sized for
+    // the widest row of THAT run, so the short reads of a mixed batch get their 16 waves per CU, and
+    // runs without windows wider than 33 run the two-block matrix loop.  No class table: one run.
+    const sk_seg_class whole = {0u, a->n_tiles, a->stride, 1u};
+    if (!classes || n_classes == 0) {
+        classes = &whole;
+        n_classes = 1;
+    }
+    for (uint32_t c = 0; c < n_classes; ++c) {
+        const sk_seg_class &k = classes[c];
+        if (k.n_tiles == 0) continue;
+        if ((uint64_t)k.first_tile + k.n_tiles > a->n_tiles || k.max_stride == 0 || k.max_stride % 8 != 0) return hipErrorInvalidValue;
+        const uint32_t lds_bytes = 64u * k.max_stride + SK_TILE_SLACK;
+        if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
+        int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+        if (per_cu > 16) per_cu = 16;
+        uint64_t grid = (uint64_t)cu_count * per_cu;
+        if (grid > k.n_tiles) grid = k.n_tiles;
+        sk_scan_args as = *a;
+        as.buf_bytes = lds_bytes;
+        as.n_tiles = k.n_tiles;
+        auto launch = [&](auto kern) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq,
+                               (const uint32_t *)nullptr, out, errword, as, tiles + k.first_tile, out_index);
+            return hipGetLastError();
+        };
+        hipError_t e;
+        if (a->truncn) e = k.wide ? launch(sk_scan_tile_kernel<true, true, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, true, true, 1, 0, 2>);
+        else e = k.wide ? launch(sk_scan_tile_kernel<true, false, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, false, true, 1, 0, 2>);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Batches whose rows start at any byte address.  offsets == lengths == nullptr: packed uniform
+// batch (a->stride any value >= a->read_len).  Otherwise ragged (offsets, or stride + lengths).
+// a->buf_bytes = the LDS bytes of a wave (sized by the caller for the longest read it expects); the
+// tiles this kernel leaves (image too large for the buffer; never in a packed uniform batch) are taken
+// by sk_launch_wave with the same a->buf_bytes.
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                    const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream)
 {
-    // a->stride = the largest row stride of the batch: sizes the one LDS buffer of each wave
-    const uint32_t lds_bytes = 64u * a->stride + SK_TILE_SLACK;
-    if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
+    const bool uniform = offsets == nullptr && lengths == nullptr;
+    const uint32_t lds_bytes = a->buf_bytes;
+    if (lds_bytes == 0 || lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
     if (per_cu > 16) per_cu = 16;
+    const uint64_t n_tiles = (a->n_reads + 63) >> 6;
     uint64_t grid = (uint64_t)cu_count * per_cu;
-    if (grid > a->n_tiles) grid = a->n_tiles;
+    if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return hipSuccess;
     auto launch = [&](auto kern) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq,
-                           (const uint32_t *)nullptr, out, errword, *a, tiles, out_index);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
+                           errword, *a);
         return hipGetLastError();
     };
-    if (a->truncn) return launch(sk_scan_tile_kernel<true, true, true, 1, 0, true>);
-    return launch(sk_scan_tile_kernel<true, false, true, 1, 0, true>);
+    const uint32_t wu = a->read_len / 10 ? a->read_len / 10 : a->read_len;
+    const bool mfma = uniform && wu <= 65 && a->read_len > 0;
+    if (a->truncn) {
+        if (mfma) return launch(sk_scan_tile_any_kernel<true, true, true>);
+        if (uniform) return launch(sk_scan_tile_any_kernel<true, true, false>);
+        return launch(sk_scan_tile_any_kernel<false, true, false>);
+    }
+    if (mfma) return launch(sk_scan_tile_any_kernel<true, false, true>);
+    if (uniform) return launch(sk_scan_tile_any_kernel<true, false, false>);
+    return launch(sk_scan_tile_any_kernel<false, false, false>);
 }
 
 // diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py).
@@ -1027,7 +1279,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wave(const
                                      const sk_scan_args *a, int cu_count, hipStream_t stream)
 {
     const uint64_t waves_per_block = SK_WAVE_THREADS / 64;
-    const uint64_t blocks_needed = (a->n_reads + waves_per_block - 1) / waves_per_block;
+    const uint64_t n_groups = (a->n_reads + 63) >> 6; // a wave takes 64 consecutive reads at a time
+    const uint64_t groups = n_groups > a->first_group ? n_groups - a->first_group : 0;
+    const uint64_t blocks_needed = (groups + waves_per_block - 1) / waves_per_block;
     uint64_t grid = (uint64_t)cu_count * 8;
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid == 0) return hipSuccess;

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_tables_match_reference_constants():
     lib = capi.lib()
-    assert lib.sk_abi_version() == 1
+    assert lib.sk_abi_version() == 2
     want = {0: (0, 4, 60), 1: (33, 33, 126), 2: (64, 58, 112), 3: (64, 64, 110)}  # reference src/sickle.h:85-91
     for qt, k in want.items():
         p = lib.sk_quality_constants(qt)

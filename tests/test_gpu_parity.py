@@ -50,10 +50,13 @@ def test_kernel_selection():
     assert capi.lib().sk_kernel_for(b) == 1  # longer rows
     assert capi.lib().sk_kernel_name(4) == b"sk_scan_tile_staged_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 150, 150, None, 10)
-    assert capi.lib().sk_kernel_for(b) == 2
+    assert capi.lib().sk_kernel_for(b) == 5  # packed rows (stride not a multiple of 8): tiles with rows at any address
     off = np.zeros(2, dtype=np.uint64)
     b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 0, 0, None, 1)
-    assert capi.lib().sk_kernel_for(b) == 2
+    assert capi.lib().sk_kernel_for(b) == 5  # ragged: the same kernel, per-lane lengths
+    b = capi.Batch(q.ctypes.data, None, None, 600, 600, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 2  # rows beyond the tile kernels: general kernel
+    assert capi.lib().sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
 
 
 @pytest.mark.parametrize("layout", ["tile", "wave_ragged", "wave_stride"])

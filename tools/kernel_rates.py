@@ -50,7 +50,9 @@ report("tile valu, per-read lengths (all 150)", timeit(lambda: ctx.scan_device_a
 pk = q[:, :L].contiguous()
 off = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
 torch.cuda.synchronize()
-report("wave kernel, ragged offsets (all 150)", timeit(lambda: ctx.scan_device_async(p, pk.data_ptr(), out.data_ptr(), n, offsets_ptr=off.data_ptr(), stream=s.cuda_stream), 3), n, n * 158)
+report("ragged offsets (all 150), hint 150", timeit(lambda: ctx.scan_device_async(p, pk.data_ptr(), out.data_ptr(), n, offsets_ptr=off.data_ptr(), stride=150, stream=s.cuda_stream), 10), n, n * 158)
+report("ragged offsets (all 150), no hint", timeit(lambda: ctx.scan_device_async(p, pk.data_ptr(), out.data_ptr(), n, offsets_ptr=off.data_ptr(), stream=s.cuda_stream), 10), n, n * 158)
+report("packed uniform 150 (stride 150)", timeit(lambda: ctx.scan_device_async(p, pk.data_ptr(), out.data_ptr(), n, stride=150, read_len=150, stream=s.cuda_stream), 10), n, n * 158)
 del pk, off, seq
 # mixed lengths 75..301
 m = 4_000_000
