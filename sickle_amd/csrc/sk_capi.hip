@@ -138,7 +138,8 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
     a->tile_order = order;
     a->buf_bytes = 0;
-    a->first_group = 0;
+    a->team_rbuf = 0;
+    a->team_maxlen = 0;
     return SK_OK;
 }
 
@@ -194,9 +195,9 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)
-        if (ragged) SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
+        if (ragged) SK_HIP(ctx, sk_launch_team(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, b->stride, ctx->cu_count, stream));
     } else {
-        SK_HIP(ctx, sk_launch_wave(b->qual, seq, b->offsets, b->lengths, out, d_err, a, ctx->cu_count, stream));
+        SK_HIP(ctx, sk_launch_team(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->read_len, ctx->cu_count, stream));
     }
     return SK_OK;
 }
@@ -443,7 +444,7 @@ const char *sk_kernel_name(int which)
 {
     switch (which) {
     case 1: return "sk_scan_tile_kernel";
-    case 2: return "sk_scan_wave_kernel";
+    case 2: return "sk_scan_team_kernel";
     case 3: return "sk_scan_tile_kernel";
     case 4: return "sk_scan_tile_staged_kernel";
     case 5: return "sk_scan_tile_any_kernel";

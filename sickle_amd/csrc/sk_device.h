@@ -10,7 +10,6 @@
 #define SK_TILE_THREADS 256
 #define SK_TILE_WAVES (SK_TILE_THREADS / 64)
 #define SK_TILE_SLACK 128u /* bytes a lane may read past its tile (the lead stream runs ahead) */
-#define SK_WAVE_THREADS 256
 #define SK_LDS_PER_CU (160u * 1024u)
 #define SK_TILE_NBUF_DEFAULT 1 /* LDS buffers per wave for the quality tile (see sk_kernels.hip) */
 #define SK_MAX_READ_LEN_DEV (1u << 24) /* == SK_MAX_READ_LEN of the C ABI */
@@ -47,7 +46,8 @@ struct sk_scan_args {
     uint32_t n_tiles;   // segmented batches: number of tile descriptors
     int32_t tile_order; // diagnostic (SK_TILE_ORDER): 0 = tile t on workgroup t mod G, 1 = contiguous tile ranges per XCD
     uint32_t buf_bytes; // LDS bytes per wave (segmented / rows at any address); general kernel: != 0 = only the tiles that do not fit them
-    uint64_t first_group; // general kernel: first 64-read group to look at
+    uint32_t team_rbuf;   // general kernel: LDS bytes of one read's buffer
+    uint32_t team_maxlen; // general kernel: the longest read that goes through LDS
 };
 
 // internal to libsickle_amd.so (not part of the C ABI)
@@ -59,9 +59,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
                                     const uint32_t *out_index, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, const sk_seg_class *classes, uint32_t n_classes,
                                     int cu_count, hipStream_t stream);
-extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
-                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
+                                     const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream);

@@ -937,116 +937,403 @@ sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------
-// General kernel: wave per read, any layout.
+// General kernel: a TEAM of lanes per read (16 or 64), any layout, any length.
+//
+// Takes what the lane-per-read kernels cannot: rows too long for a 64-read LDS tile.  The reads of
+// a wave (4 with teams of 16, 1 with teams of 64) are staged whole into LDS by the entire wave --
+// 16 bytes per lane per LDS-DMA, source address per lane, so the image of each read starts on an
+// aligned boundary whatever its address in the batch.  Then lane tl of a team owns the c bytes
+// [tl*c, tl*c + c) of its read (c a multiple of 4 with c/4 odd: the lanes' dword walks spread over
+// the banks) and the windows that START there:
+//   1. range check (two v_sad_u8 per dword) and byte sum of its chunk; inclusive scan of the chunk
+//      sums over the team: P(x) for every chunk boundary x;
+//   2. S_s - T for its first window from the prefix: P(s + w) - P(s), the first taken from the lane
+//      w/c chunks up plus a partial chunk sum -- no lane adds up w bytes;
+//   3. the windows, 4 per dword of the trailing and the leading stream with byte-parallel arithmetic
+//      (the vector-ALU path of the tile kernel), 32 per trip: first >= T, first < T, first < T after
+//      the lane's first >= T;
+//   4. team min-reductions give i0 and i1; the two in-window searches and the N rule stride the
+//      team over dwords; lane 0 of the team stores the cut.
+// A read too long for the wave's LDS buffer is scanned straight from global memory by the whole
+// wave (scan_read_global: the same algorithm byte by byte; correctness path).
+// With a.buf_bytes != 0 the kernel takes only the 64-read tiles sk_scan_tile_any_kernel left.
 // ------------------------------------------------------------------------------------------
+namespace {
+
+template <int TEAM>
+__device__ __forceinline__ int team_min(int v)
+{
+#pragma unroll
+    for (int o = TEAM / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int TEAM>
+__device__ __forceinline__ uint32_t team_or(uint32_t v)
+{
+#pragma unroll
+    for (int o = TEAM / 2; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+template <int TEAM>
+__device__ __forceinline__ uint32_t team_scan_add(uint32_t v, int tl) // inclusive
+{
+#pragma unroll
+    for (int o = 1; o < TEAM; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o, TEAM);
+        if (tl >= o) v += t;
+    }
+    return v;
+}
+
+// one read, the whole wave, from global memory: reference trim.cpp:3-116 with the closed form of this
+// file's header, byte by byte.  Returns the cut (the same value in every lane).
 template <bool HAS_SEQ>
-__global__ void __launch_bounds__(SK_WAVE_THREADS)
-sk_scan_wave_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+__device__ __forceinline__ sk_cut_dev scan_read_global(const uint8_t *__restrict__ q, const uint8_t *__restrict__ sq, int L,
+                                                    uint64_t r, int lane, const sk_scan_args &a, unsigned long long *errword)
+{
+    int five = -1, three = -1;
+    if (L > 0 && L >= a.lthr) { // trim.cpp:21
+        int w = L / 10;
+        if (w == 0) w = L;
+        const int nwin = L - w + 1;
+        const int T = a.craw * w;
+
+        // first bad char of the whole read (lanes stride the bytes, coalesced)
+        int pbad = INF;
+        for (int j = lane; j < L; j += 64) {
+            const int c = (int)(int8_t)q[j];
+            if ((c < a.qmin || c > a.qmax) && pbad == INF) pbad = j;
+        }
+        pbad = wave_min(pbad);
+
+        // lane owns windows [s, e): seeds the sum, then rolls it (trim.cpp:76-80)
+        const int per = (nwin + 63) >> 6;
+        const int s = lane * per;
+        const int e = min(nwin, s + per);
+        int fa = INF, fb = INF, fc = INF; // first >=T, first <T, first <T after fa
+        if (s < e) {
+            int tot = 0;
+            for (int j = 0; j < w; ++j) tot += q[s + j];
+            for (int i = s; i < e; ++i) {
+                if (tot >= T) {
+                    if (fa == INF) fa = i;
+                } else {
+                    if (fb == INF) fb = i;
+                    if (fa != INF && fc == INF) fc = i;
+                }
+                if (i + 1 < e) tot += (int)q[i + w] - (int)q[i];
+            }
+        }
+        const int i0 = a.no5 ? -1 : wave_min(fa);
+        const bool found5 = a.no5 || i0 != INF;
+        int cand = INF;
+        if (a.no5) cand = fb;
+        else if (i0 != INF && s < e) cand = (s > i0) ? fb : (fa == i0 ? fc : INF);
+        const int i1 = wave_min(cand);
+        const bool done = found5 && i1 != INF;
+
+        five = 0;
+        three = L;
+        if (!a.no5 && i0 != INF) { // trim.cpp:46-51
+            int hit = INF;
+            for (int j = lane; j < w && hit == INF; j += 64)
+                if ((int)q[i0 + j] >= a.cthr_raw) hit = i0 + j;
+            five = wave_min(hit);
+            if (five == INF) five = 0;
+        }
+        if (done) { // trim.cpp:65-70
+            int hit = INF;
+            for (int j = lane; j < w && hit == INF; j += 64)
+                if ((int)q[i1 + j] < a.cthr_raw) hit = i1 + j;
+            three = wave_min(hit);
+            if (three == INF) three = L;
+        }
+        const int touched = done ? i1 + w : L;
+        if (pbad < touched) {
+            if (lane == 0) report_error(errword, r, pbad, (int)(int8_t)q[pbad]);
+        }
+        if (HAS_SEQ) { // trim.cpp:86-98
+            int ni = INF, Ni = INF;
+            for (int j = lane; j < L; j += 64) {
+                const uint8_t c = sq[j];
+                if (c == 'n' && ni == INF) ni = j;
+                if (c == 'N' && Ni == INF) Ni = j;
+            }
+            ni = wave_min(ni);
+            Ni = wave_min(Ni);
+            if (ni != INF) three = ni - 1;
+            else if (Ni != INF) three = -2;
+        }
+        if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
+            five = -1;
+            three = -1;
+        }
+    }
+    return sk_cut_dev{five, three};
+}
+
+} // namespace
+
+template <int TEAM, bool HAS_SEQ>
+__global__ void __launch_bounds__(64)
+sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
                     sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * SK_WAVE_THREADS + threadIdx.x) >> 6;
-    const uint64_t wave_count = ((uint64_t)gridDim.x * SK_WAVE_THREADS) >> 6;
-    const uint64_t n_groups = (a.n_reads + 63) >> 6;
-    // a.buf_bytes != 0: only the 64-read tiles sk_scan_tile_any_kernel left (same test as there)
+    static_assert(TEAM == 16 || TEAM == 64, "teams of 16 or 64 lanes");
+    constexpr int RPW = 64 / TEAM; // reads per wave
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x; // single-wave workgroups
+    const int g = lane / TEAM, tl = lane % TEAM;
+    // a read's buffer: rbuf bytes (the longest read the LDS path takes + what the lead stream may read
+    // past it), the teams' buffers 80 bytes apart on top so that their rows do not share banks
+    const uint32_t rbuf = a.team_rbuf, pitch = rbuf + 80u;
+    const uint32_t *row32 = reinterpret_cast<const uint32_t *>(lds + (uint32_t)g * pitch);
+    const uint8_t *rowb = lds + (uint32_t)g * pitch;
+    const uint64_t n_slots = (a.n_reads + RPW - 1) / RPW;
+    const uint64_t batch_end = a.n_reads ? rag_batch_end(offsets, lengths, a) : 0;
+    const uint32_t min4 = splat((uint32_t)a.qmin), max4 = splat((uint32_t)a.qmax);
+    const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));
+    const uint32_t cthr4 = splat((uint32_t)a.cthr);
+    const int range = a.qmax - a.qmin;
 
-    for (uint64_t grp = a.first_group + wave_global; grp < n_groups; grp += wave_count) {
-      if (a.buf_bytes && rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes)) continue;
-      const uint64_t r_end = min(a.n_reads, (grp + 1) << 6);
-      for (uint64_t r = grp << 6; r < r_end; ++r) {
-        uint64_t off;
-        int L;
+    auto do_slot = [&](uint64_t slot) {
+        const uint64_t r = slot * RPW + g;
+        const bool valid = r < a.n_reads;
+        const uint64_t rc = min(r, a.n_reads - 1);
+        uint64_t o, e;
         if (offsets) {
-            off = offsets[r];
-            const uint64_t end = offsets[r + 1];
-            L = end >= off ? (int)min(end - off, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
+            o = offsets[rc];
+            e = offsets[rc + 1];
         } else {
-            off = r * a.stride;
-            L = lengths ? (int)lengths[r] : (int)a.read_len;
+            o = rc * a.stride;
+            e = o + (lengths ? lengths[rc] : a.read_len);
         }
-        const uint8_t *q = qual + off;
-        int five = -1, three = -1;
-        if (L > 0 && L >= a.lthr) { // trim.cpp:21
-            int w = L / 10;
-            if (w == 0) w = L;
-            const int nwin = L - w + 1;
-            const int T = a.craw * w;
+        const int L = (valid && e >= o) ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
+        const bool big = L > (int)a.team_maxlen; // not through LDS
+        const bool scan = L > 0 && L >= a.lthr && !big; // trim.cpp:21
 
-            // first bad char of the whole read (lanes stride the bytes, coalesced)
-            int pbad = INF;
-            for (int j = lane; j < L; j += 64) {
-                const int c = (int)(int8_t)q[j];
-                if ((c < a.qmin || c > a.qmax) && pbad == INF) pbad = j;
-            }
-            pbad = wave_min(pbad);
-
-            // lane owns windows [s, e): seeds the sum, then rolls it (trim.cpp:76-80)
-            const int per = (nwin + 63) >> 6;
-            const int s = lane * per;
-            const int e = min(nwin, s + per);
-            int fa = INF, fb = INF, fc = INF; // first >=T, first <T, first <T after fa
-            if (s < e) {
-                int tot = 0;
-                for (int j = 0; j < w; ++j) tot += q[s + j];
-                for (int i = s; i < e; ++i) {
-                    if (tot >= T) {
-                        if (fa == INF) fa = i;
-                    } else {
-                        if (fb == INF) fb = i;
-                        if (fa != INF && fc == INF) fc = i;
+        // ---- the reads of this wave into LDS, read after read, the whole wave copying: lane i of a
+        // piece fetches the 16 bytes at read offset 16*(c0 + i), wherever they are in the batch
+        auto stage = [&](const uint8_t *base) {
+#pragma unroll
+            for (int gg = 0; gg < RPW; ++gg) {
+                const int Lg = __builtin_amdgcn_readlane(scan ? L : 0, gg * TEAM);
+                if (Lg == 0) continue;
+                const uint64_t og = readlane_u64(o, gg * TEAM);
+                uint8_t *dst = lds + (uint32_t)gg * pitch;
+                const uint8_t *src = base + og;
+                const uint32_t nch = ((uint32_t)Lg + 15u) >> 4;
+                for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
+                    const uint32_t so = 16u * (c0 + (uint32_t)lane);
+                    if (c0 + (uint32_t)lane < nch) {
+                        if (og + so + 16u <= batch_end) {
+                            __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + c0 * 16u), 16, 0, SK_DMA_AUX);
+                        } else { // the batch ends inside this chunk: byte by byte
+                            for (uint32_t j = 0; j < 16u && og + so + j < batch_end; ++j) dst[so + j] = src[so + j];
+                        }
                     }
-                    if (i + 1 < e) tot += (int)q[i + w] - (int)q[i];
                 }
             }
-            const int i0 = a.no5 ? -1 : wave_min(fa);
-            const bool found5 = a.no5 || i0 != INF;
-            int cand = INF;
-            if (a.no5) cand = fb;
-            else if (i0 != INF && s < e) cand = (s > i0) ? fb : (fa == i0 ? fc : INF);
-            const int i1 = wave_min(cand);
-            const bool done = found5 && i1 != INF;
+            wait_vmcnt(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        stage(qual);
 
-            five = 0;
-            three = L;
-            if (!a.no5 && i0 != INF) { // trim.cpp:46-51
-                int hit = INF;
-                for (int j = lane; j < w && hit == INF; j += 64)
-                    if ((int)q[i0 + j] >= a.cthr_raw) hit = i0 + j;
-                five = wave_min(hit);
-                if (five == INF) five = 0;
+        int five = -1, three = -1;
+        int w = L / 10; // trim.cpp:8
+        if (w == 0) w = L; // trim.cpp:30
+        const int nwin = scan ? L - w + 1 : 0;
+        const int T = a.craw * w;
+        // this lane's chunk of the read
+        const int c4 = scan ? ((((L + TEAM - 1) / TEAM + 3) >> 2) | 1) : 1;
+        const int c = 4 * c4;
+        const int s = tl * c;
+        const int sdw = s >> 2;
+
+        // ---- 1. range check + chunk sum (trim.cpp:129 and the prefix of 31-33)
+        const int c4max = __builtin_amdgcn_readfirstlane(wave_max(scan ? c4 : 0));
+        uint32_t sad = 0, csum = 0;
+        for (int k = 0; k < c4max; ++k) {
+            uint32_t x = min4;
+            int nval = 0;
+            if (scan && k < c4) {
+                x = row32[sdw + k];
+                nval = L - (s + 4 * k);
             }
-            if (done) { // trim.cpp:65-70
-                int hit = INF;
-                for (int j = lane; j < w && hit == INF; j += 64)
-                    if ((int)q[i1 + j] < a.cthr_raw) hit = i1 + j;
-                three = wave_min(hit);
-                if (three == INF) three = L;
-            }
-            const int touched = done ? i1 + w : L;
-            if (pbad < touched) {
-                if (lane == 0) report_error(errword, r, pbad, (int)(int8_t)q[pbad]);
-            }
-            if (HAS_SEQ) { // trim.cpp:86-98
-                const uint8_t *sq = seq + off;
-                int ni = INF, Ni = INF;
-                for (int j = lane; j < L; j += 64) {
-                    const uint8_t c = sq[j];
-                    if (c == 'n' && ni == INF) ni = j;
-                    if (c == 'N' && Ni == INF) Ni = j;
+            const uint32_t xq = first_bytes(x, nval, min4);
+            sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+            sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+            csum = __builtin_amdgcn_sad_u8(first_bytes(x, nval, 0u), 0u, csum);
+        }
+        const bool bad = scan && sad != (uint32_t)(4 * c4max * range);
+        const uint32_t incl = team_scan_add<TEAM>(csum, tl);
+
+        // ---- 2. S_s - T for this lane's first window: P(s + w) - P(s) - T
+        const bool has_win = scan && s < nwin;
+        const int dq = w / c, rem = w - dq * c;
+        const int kq = tl + dq; // the chunk position s + w lies in
+        const uint32_t below = (uint32_t)__shfl((int)incl, g * TEAM + min(max(kq - 1, 0), TEAM - 1), 64);
+        uint32_t part = 0;
+        {
+            const int remmax = __builtin_amdgcn_readfirstlane(wave_max(has_win ? rem : 0));
+            const int bdw = (kq * c) >> 2;
+            for (int j = 0; 4 * j < remmax; ++j)
+                if (has_win && 4 * j < rem) part = __builtin_amdgcn_sad_u8(first_bytes(row32[bdw + j], rem - 4 * j, 0u), 0u, part);
+        }
+        int v = (int)((kq >= 1 ? below : 0u) + part) - (int)(incl - csum) - T; // sign bit <=> window average below the threshold
+
+        // ---- 3. the lane's windows [s, we), 32 per trip: trim.cpp:34-81 without the breaks
+        const int we = min(s + c, nwin);
+        uint32_t fa = NONE, fb = NONE, fc = NONE; // first >= T, first < T, first < T after fa (window indices)
+        {
+            const int mytrips = has_win ? (we - s + 31) >> 5 : 0;
+            const int tripmax = __builtin_amdgcn_readfirstlane(wave_max(mytrips));
+            const int ldw = (s + w) >> 2;
+            const uint32_t sh = (uint32_t)(w & 3); // s is a multiple of 4
+            uint32_t lead_lo = has_win ? row32[ldw] : 0u;
+            for (int tr = 0; tr < tripmax; ++tr) {
+                if (tr < mytrips) {
+                    uint32_t M = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int dwi = tr * 8 + k;
+                        const uint32_t y = row32[sdw + dwi];              // chars leaving the window
+                        const uint32_t lead_hi = row32[ldw + dwi + 1];
+                        const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, sh); // chars entering
+                        lead_lo = lead_hi;
+                        const int d = (int)(((x | H4) - y) ^ H4); // per byte: x - y as int8 (both < 128)
+                        const int t1 = __builtin_amdgcn_sdot4(d, 0x00000001, v, false);
+                        const int t2 = __builtin_amdgcn_sdot4(d, 0x00000101, v, false);
+                        const int t3 = __builtin_amdgcn_sdot4(d, 0x00010101, v, false);
+                        const int t4 = __builtin_amdgcn_sdot4(d, 0x01010101, v, false);
+                        M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
+                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
+                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
+                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
+                        v = t4;
+                    }
+                    // bit (31 - j) of M: window base + j is below the threshold
+                    const int base = s + 32 * tr;
+                    const int nv = we - base;
+                    const uint32_t vmask = nv >= 32 ? ~0u : ~(~0u >> nv); // nv >= 1 here
+                    const uint32_t lt = M & vmask, ge = ~M & vmask;
+                    fa = min(fa, __builtin_elementwise_add_sat(ffbh_or_none(ge), (uint32_t)base));
+                    fb = min(fb, __builtin_elementwise_add_sat(ffbh_or_none(lt), (uint32_t)base));
+                    // windows of this trip strictly after fa: the low (base + 31 - fa) bits
+                    const uint32_t width = __builtin_elementwise_sub_sat((uint32_t)(base + 31), fa);
+                    const uint32_t low = (1u << (width & 31u)) - 1u;
+                    const uint32_t after = lt & (width >= 32u ? ~0u : low);
+                    fc = min(fc, __builtin_elementwise_add_sat(ffbh_or_none(after), (uint32_t)base));
                 }
-                ni = wave_min(ni);
-                Ni = wave_min(Ni);
-                if (ni != INF) three = ni - 1;
-                else if (Ni != INF) three = -2;
-            }
-            if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
-                five = -1;
-                three = -1;
             }
         }
-        if (lane == 0) out[r] = sk_cut_dev{five, three};
-      }
+
+        // ---- 4. the team's windows: trim.cpp:42 and :61
+        const int fai = fa == NONE ? INF : (int)fa, fbi = fb == NONE ? INF : (int)fb, fci = fc == NONE ? INF : (int)fc;
+        const int i0 = a.no5 ? INF : team_min<TEAM>(fai);
+        const bool have5 = !a.no5 && i0 != INF;
+        const bool found5 = a.no5 || i0 != INF;
+        int cand = INF;
+        if (a.no5) cand = fbi;
+        else if (i0 != INF && has_win) cand = (s > i0) ? fbi : (fai == i0 ? fci : INF);
+        const int i1 = team_min<TEAM>(cand);
+        const bool done = found5 && i1 != INF;
+
+        five = 0;
+        three = L;
+        if (have5) { // trim.cpp:46-51: the first char >= threshold at or after i0 (one exists inside the window)
+            int hit = INF;
+            const int d0 = i0 >> 2, ndw = ((i0 & 3) + w + 3) >> 2;
+            for (int d = tl; d < ndw && hit == INF; d += TEAM) {
+                uint32_t f = ge_flags(row32[d0 + d], cthr4);
+                if (d == 0) f &= ~0u << (8 * (i0 & 3));
+                if (f) hit = 4 * (d0 + d) + (__builtin_ctz(f) >> 3);
+            }
+            hit = team_min<TEAM>(hit);
+            five = hit == INF ? 0 : hit;
+        }
+        if (done) { // trim.cpp:65-70
+            int hit = INF;
+            const int d0 = i1 >> 2, ndw = ((i1 & 3) + w + 3) >> 2;
+            for (int d = tl; d < ndw && hit == INF; d += TEAM) {
+                uint32_t f = ge_flags(row32[d0 + d], cthr4) ^ H4;
+                if (d == 0) f &= ~0u << (8 * (i1 & 3));
+                if (f) hit = 4 * (d0 + d) + (__builtin_ctz(f) >> 3);
+            }
+            hit = team_min<TEAM>(hit);
+            three = hit == INF ? L : hit;
+        }
+
+        // ---- range error: only if the first bad char is one the reference would have read
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+            int pb = INF;
+            if (bad) {
+                for (int k = 0; k < c4 && pb == INF; ++k) {
+                    const uint32_t f = keep_first(bad_flags(row32[sdw + k], min4, hi4), L - (s + 4 * k));
+                    if (f) pb = s + 4 * k + (__builtin_ctz(f) >> 3);
+                }
+            }
+            pb = team_min<TEAM>(pb);
+            const int touched = done ? i1 + w : L;
+            if (scan && pb < touched && tl == 0) report_error(errword, r, pb, (int)(int8_t)rowb[pb]);
+        }
+
+        // ---- the N rule: trim.cpp:86-98, the sequences through the same buffers
+        if (HAS_SEQ) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage(seq);
+            uint32_t nlo = NONE, anyN = 0; // bit index of the first lowercase n; any uppercase N
+            const int c4m = __builtin_amdgcn_readfirstlane(wave_max(scan ? c4 : 0));
+            for (int k = 0; k < c4m; ++k) {
+                if (scan && k < c4) {
+                    const uint32_t x = first_bytes(row32[sdw + k], L - (s + 4 * k), 0u);
+                    const uint32_t y = (x | 0x20202020u) ^ 0x6e6e6e6eu;
+                    const uint32_t either = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & H4;
+                    const uint32_t lower = either & (x << 2); // bit 5 of the byte moved onto its flag
+                    nlo = min(nlo, __builtin_elementwise_add_sat(ffbl_or_none(lower), (uint32_t)(8 * (s + 4 * k))));
+                    anyN |= either ^ lower;
+                }
+            }
+            const int nl = team_min<TEAM>(nlo == NONE ? INF : (int)(nlo >> 3));
+            anyN = team_or<TEAM>(anyN);
+            if (nl != INF) three = nl - 1;
+            else if (anyN) three = -2;
+        }
+        if (!scan || !found5 || (three - five < a.lthr)) { // trim.cpp:103-108
+            five = -1;
+            three = -1;
+        }
+        if (valid && !big && tl == 0) out[r] = sk_cut_dev{five, three};
+        // every LDS read of this slot is done before the next slot's DMA may overwrite the buffers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // ---- reads too long for the LDS buffer: the whole wave, one after the other, from global memory
+        if (__builtin_amdgcn_ballot_w64(big)) {
+#pragma unroll
+            for (int gg = 0; gg < RPW; ++gg) {
+                if (!__builtin_amdgcn_readlane((int)big, gg * TEAM)) continue;
+                const int Lg = __builtin_amdgcn_readlane(L, gg * TEAM);
+                const uint64_t og = readlane_u64(o, gg * TEAM);
+                const uint64_t rg = slot * RPW + gg;
+                const sk_cut_dev cut = scan_read_global<HAS_SEQ>(qual + og, HAS_SEQ ? seq + og : nullptr, Lg, rg, lane, a, errword);
+                if (lane == 0) out[rg] = cut;
+            }
+        }
+    };
+
+    if (a.buf_bytes) {
+        // only the 64-read tiles sk_scan_tile_any_kernel left (the same test as there)
+        const uint64_t n_groups = (a.n_reads + 63) >> 6;
+        for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+            if (rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes)) continue;
+            for (uint64_t sub = 0; sub < (uint64_t)(64 / RPW); ++sub) {
+                const uint64_t slot = grp * (64 / RPW) + sub;
+                if (slot < n_slots) do_slot(slot);
+            }
+        }
+    } else {
+        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) do_slot(slot);
     }
 }
 
@@ -1274,22 +1561,42 @@ extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cu
 #undef SK_GO
 }
 
-extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wave(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
-                                     const sk_scan_args *a, int cu_count, hipStream_t stream)
+                                     const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
 {
-    const uint64_t waves_per_block = SK_WAVE_THREADS / 64;
-    const uint64_t n_groups = (a->n_reads + 63) >> 6; // a wave takes 64 consecutive reads at a time
-    const uint64_t groups = n_groups > a->first_group ? n_groups - a->first_group : 0;
-    const uint64_t blocks_needed = (groups + waves_per_block - 1) / waves_per_block;
-    uint64_t grid = (uint64_t)cu_count * 8;
-    if (grid > blocks_needed) grid = blocks_needed;
+    // max_len = the longest read the caller expects (0 = unknown).  Teams of 16 lanes (4 reads per
+    // wave) up to 2 KiB, the whole wave beyond; reads longer than the buffer sized here still come out
+    // right, from global memory (scan_read_global).
+    if (a->n_reads == 0) return hipSuccess;
+    if (max_len == 0) max_len = 32768;
+    static const uint64_t team16_max = [] { const char *e = getenv("SK_TEAM16_MAX"); return e ? (uint64_t)atoll(e) : 4096ull; }();
+    const int team = max_len <= team16_max ? 16 : 64;
+    const int rpw = 64 / team;
+    uint64_t cap = max_len;
+    const uint64_t cap_max = (uint64_t)(SK_LDS_PER_CU / 2) / rpw - 1024; // at least two waves per CU
+    if (cap > cap_max) cap = cap_max;
+    sk_scan_args at = *a;
+    at.team_maxlen = (uint32_t)cap;
+    // what the lead stream and the 32-window trips may read past the read: a chunk + 32 windows + slack
+    at.team_rbuf = (uint32_t)((cap + cap / team + 4 + 32 + SK_TILE_SLACK + 15) & ~(uint64_t)15);
+    const uint32_t lds_bytes = (uint32_t)rpw * (at.team_rbuf + 80u);
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    const uint64_t n_slots = (a->n_reads + rpw - 1) / rpw;
+    const uint64_t work = a->buf_bytes ? (a->n_reads + 63) >> 6 : n_slots; // tiles to look at, or slots
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    if (grid > work) grid = work;
     if (grid == 0) return hipSuccess;
-    if (a->truncn)
-        hipLaunchKernelGGL(sk_scan_wave_kernel<true>, dim3((unsigned)grid), dim3(SK_WAVE_THREADS), 0, stream, qual, seq,
-                           offsets, lengths, out, errword, *a);
-    else
-        hipLaunchKernelGGL(sk_scan_wave_kernel<false>, dim3((unsigned)grid), dim3(SK_WAVE_THREADS), 0, stream, qual,
-                           seq, offsets, lengths, out, errword, *a);
-    return hipGetLastError();
+    auto launch = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
+                           errword, at);
+        return hipGetLastError();
+    };
+    if (team == 16) return a->truncn ? launch(sk_scan_team_kernel<16, true>) : launch(sk_scan_team_kernel<16, false>);
+    return a->truncn ? launch(sk_scan_team_kernel<64, true>) : launch(sk_scan_team_kernel<64, false>);
 }
