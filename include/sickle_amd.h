@@ -201,6 +201,12 @@ int sk_kernel_for(const sk_batch *batch);
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */
 const char *sk_kernel_name(int which);
 
+/* Measurement aid (bench.py's second roofline denominator): streams `bytes` of device memory at
+ * dev_buf through a read-only kernel (16-byte nt loads, nothing written) `launches` times on
+ * hip_stream and returns the average rate in GB/s, timed with HIP events on that stream. */
+int sk_probe_read_bandwidth(sk_ctx *ctx, const void *dev_buf, size_t bytes, int launches, void *hip_stream,
+                            double *gb_per_s);
+
 /* ---- BGZF block deflate for the -g writer (no counterpart in the reference, whose -g hands the
  * records to gzprintf, src/trim_single.cpp:418).  text: n_blocks blocks at a stride of 65280 bytes,
  * block b holding sizes[b] (<= 65280) bytes (the buffer may end with the last block's bytes); out: n_blocks slots of 65536 bytes; out_sizes[b] = the

@@ -16,7 +16,7 @@ QUALTYPES = {"phred": 0, "sanger": 1, "solexa": 2, "illumina": 3}
 EXPORTS = ("sk_quality_constants", "sk_typename", "sk_abi_version", "sk_device_count", "sk_create",
            "sk_destroy", "sk_last_error", "sk_device", "sk_host_alloc", "sk_host_free",
            "sk_scan_device_async", "sk_scan_device_finish", "sk_trim_batch", "sk_submit", "sk_wait",
-           "sk_kernel_for", "sk_kernel_name", "sk_seg_classes", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
+           "sk_kernel_for", "sk_kernel_name", "sk_seg_classes", "sk_probe_read_bandwidth", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
            "sk_bgzf_last_error")
 
 
@@ -118,6 +118,8 @@ def lib():
         L.sk_kernel_for.argtypes = [C.POINTER(Batch)]
         L.sk_kernel_name.restype = C.c_char_p
         L.sk_kernel_name.argtypes = [C.c_int]
+        L.sk_probe_read_bandwidth.restype = C.c_int
+        L.sk_probe_read_bandwidth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
         L.sk_seg_classes.restype = C.c_uint32
         L.sk_seg_classes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.sk_bgzf_deflate.restype = C.c_int
@@ -212,6 +214,12 @@ class Context:
                           offsets_ptr=None, lengths_ptr=None, stream=None):
         b = Batch(qual_ptr, seq_ptr, offsets_ptr, stride, read_len, lengths_ptr, n_reads)
         self._check(lib().sk_scan_device_async(self._h, C.byref(params), C.byref(b), out_ptr, stream))
+
+    def probe_read_bandwidth(self, dev_ptr, nbytes, launches=20, stream=None):
+        """GB/s of a read-only stream over [dev_ptr, dev_ptr + nbytes) on this device."""
+        g = C.c_double()
+        self._check(lib().sk_probe_read_bandwidth(self._h, dev_ptr, nbytes, launches, stream, C.byref(g)))
+        return g.value
 
     def scan_device_finish(self, stream=None):
         err = Err()

@@ -452,6 +452,28 @@ const char *sk_kernel_name(int which)
     }
 }
 
+int sk_probe_read_bandwidth(sk_ctx *ctx, const void *dev_buf, size_t bytes, int launches, void *hip_stream, double *gb_per_s)
+{
+    if (!ctx || !dev_buf || !gb_per_s || launches < 1 || bytes < (1u << 20) || (reinterpret_cast<uintptr_t>(dev_buf) & 15)) return SK_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    SK_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    SK_HIP(ctx, hipEventCreate(&e0));
+    SK_HIP(ctx, hipEventCreate(&e1));
+    uint32_t *sink = reinterpret_cast<uint32_t *>(ctx->d_err); // never written: the kernel's store is unreachable for real data
+    for (int i = 0; i < 3; ++i) SK_HIP(ctx, sk_launch_read_probe(dev_buf, bytes, sink, ctx->cu_count, stream));
+    SK_HIP(ctx, hipEventRecord(e0, stream));
+    for (int i = 0; i < launches; ++i) SK_HIP(ctx, sk_launch_read_probe(dev_buf, bytes, sink, ctx->cu_count, stream));
+    SK_HIP(ctx, hipEventRecord(e1, stream));
+    SK_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    SK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gb_per_s = ms > 0 ? (double)bytes * launches / (ms * 1e-3) / 1e9 : 0.0;
+    return SK_OK;
+}
+
 int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *batch, sk_cut *out, void *hip_stream)
 {
     if (!ctx || !out) return SK_EINVAL;

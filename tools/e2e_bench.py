@@ -66,6 +66,71 @@ def run(binary, d, tag, p1, p2, threads, gzout=False):
     return dt, [md5(o) for o in outs]
 
 
+def pick_tmp(need_bytes):
+    """A directory with room for the run: tmpfs first (the comparison is about the programs, not a disk)."""
+    import shutil
+    for d in (os.environ.get("SICKLE_E2E_TMP"), "/dev/shm", os.environ.get("TMPDIR"), "/tmp"):
+        if d and os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need_bytes:
+            return d
+    return None
+
+
+def same_files(a, b):
+    return os.path.getsize(a) == os.path.getsize(b) and subprocess.run(["cmp", "-s", a, b]).returncode == 0
+
+
+def pe_against_reference(n_pairs, threads=None):
+    """`sickle pe` of this repo (HIP) and the compiled reference CLI (oracle/_ref/sickle, -a 1 and -a threads)
+    on the same synthetic two-file input of n_pairs 150 bp pairs in tmpfs: wall times of the whole
+    processes, outputs compared byte for byte (-a 1; the reference's -a T order differs by design).
+    Reference path timed: /root/reference/src/trim_paired.cpp:265-476."""
+    res = {"pairs": n_pairs, "reads": 2 * n_pairs, "read_len": 150, "command": "sickle pe -f R1 -r R2 -t sanger -o O1 -p O2 -s OS -a T"}
+    need = n_pairs * 330 * 2 * 3 + (1 << 30)  # input + two sets of outputs
+    root = pick_tmp(need)
+    if root is None:
+        res["error"] = "no temporary directory with %d bytes free" % need
+        return res
+    if threads is None:
+        threads = min(len(os.sched_getaffinity(0)), 16)
+    with tempfile.TemporaryDirectory(dir=root) as d:
+        res["tmp"] = root
+        t0 = time.perf_counter()
+        p1, p2 = write_pair(d, n_pairs)
+        res["input_bytes"] = os.path.getsize(p1) + os.path.getsize(p2)
+        res["generate_s"] = time.perf_counter() - t0
+
+        def go(binary, tag, a):
+            outs = [os.path.join(d, "%s_%s.fastq" % (tag, k)) for k in ("o1", "o2", "os")]
+            t0 = time.perf_counter()
+            pr = subprocess.run([binary, "pe", "-f", p1, "-r", p2, "-t", "sanger", "-o", outs[0], "-p", outs[1], "-s", outs[2],
+                                 "-a", str(a)], capture_output=True)
+            dt = time.perf_counter() - t0
+            if pr.returncode != 0:
+                raise RuntimeError("%s exited %d: %s" % (binary, pr.returncode, pr.stderr.decode("latin-1")[-300:]))
+            return dt, outs
+
+        go(NEW, "warm", 1)  # first touch of the GPU runtime and of the input's pages
+        t_new, o_new = go(NEW, "new", 1)
+        res["new_s"], res["new_reads_per_s"] = t_new, 2 * n_pairs / t_new
+        res["output_bytes"] = sum(os.path.getsize(o) for o in o_new)
+        t_newn, o_newn = go(NEW, "newn", threads)
+        res["new_aN_s"] = t_newn
+        for o in o_newn:
+            os.unlink(o)
+        if os.path.exists(REF):
+            t_ref1, o_ref1 = go(REF, "ref1", 1)
+            res["ref_a1_s"], res["ref_a1_reads_per_s"] = t_ref1, 2 * n_pairs / t_ref1
+            res["byte_identical"] = all(same_files(a, b) for a, b in zip(o_new, o_ref1))
+            for o in o_ref1:
+                os.unlink(o)
+            t_refn, o_refn = go(REF, "refn", threads)
+            res["ref_aN_s"], res["ref_aN_threads"], res["ref_aN_reads_per_s"] = t_refn, threads, 2 * n_pairs / t_refn
+            res["speedup_vs_ref_a1"], res["speedup_vs_ref_aN"] = t_ref1 / t_new, t_refn / t_new
+        else:
+            res["reference"] = "oracle/_ref/sickle did not travel with the repo: reference not timed"
+    return res
+
+
 def to_bgzf(d, path):
     """A BGZF copy of a FASTQ file, made by this CLI itself: -q 0 -l 0 keeps every read whole."""
     out = path + ".bgzf.gz"
