@@ -146,7 +146,8 @@ def run_variants(torch, capi, ctx, device, stream, names, reps):
             gbs = v["algo_bytes"] / (avg * 1e-3) / 1e9
             out[name] = {"workload": v["workload"], "kernel": v["kernel"], "reads": v["n_reads"], "kernel_ms_avg": avg,
                          "kernel_ms_min": lo, "kernel_ms_max": hi, "algorithmic_bytes_per_launch": v["algo_bytes"],
-                         "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "reads_per_s": v["n_reads"] / (avg * 1e-3)}
+                         "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "reads_per_s": v["n_reads"] / (avg * 1e-3),
+                         "scans_in_run": reps + 10}
             del v
             torch.cuda.empty_cache()
         except Exception as e:  # a failing variant must not cost the headline line

@@ -41,7 +41,7 @@ void FQEntry::validate() const
         error(string("Sequence: ") + string(seq));
         error(string("Comment: ") + string(comment));
         error(string("Qualities: ") + string(qual));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     if (name[0] != '@') {
         error(string("In ") + string(name) + string("(line ") + std::to_string((position * 4) - 4) + string(")"));
@@ -49,20 +49,20 @@ void FQEntry::validate() const
         error(string("Sequence: ") + string(seq));
         error(string("Comment: ") + string(comment));
         error(string("Qualities: ") + string(qual));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     if (seq.length() < 1) {
         error("Sequence line is empty");
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     if (qual.length() < 1) {
         error("Quality line is empty.");
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     if (qual.length() != seq.length()) {
         error("Sequence and quality lines have different lengths:");
         error(string(seq));
         error(string(qual));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
 }

@@ -160,7 +160,7 @@ size_t GZReader::fill_bgzf(size_t old)
         });
         if (failed) {
             fprintf(stderr, "****Error: could not read input file '%s'.\n\n", path);
-            exit(EXIT_FAILURE);
+            fatal_exit(EXIT_FAILURE);
         }
     }
     struct Blk {
@@ -309,7 +309,7 @@ bool GZReader::fill()
             });
             if (failed) {
                 fprintf(stderr, "****Error: could not read input file '%s'.\n\n", path);
-                exit(EXIT_FAILURE);
+                fatal_exit(EXIT_FAILURE);
             }
             got = (size_t)want;
             file_pos += want;

@@ -36,4 +36,11 @@ void error(const std::string &content);
 void msg(const char *content);
 void msg(const std::string &content);
 
+// How the pipeline leaves on a fatal error (malformed record, range error, device failure).  These
+// fire on the reader, pool, flusher or main thread while other threads are inside HIP calls; exit()
+// would run the static destructors -- HIP's among them -- under live GPU work.  So: flush the two
+// stdio streams (the output files are raw descriptors, nothing of them is buffered here) and leave
+// without unwinding, like the reference's exit(1) leaves its detached threads behind.
+[[noreturn]] void fatal_exit(int status);
+
 #endif

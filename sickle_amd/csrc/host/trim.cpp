@@ -29,6 +29,15 @@ void msg(const char *content)
 }
 void msg(const std::string &content) { msg(content.c_str()); }
 
+void fatal_exit(int status)
+{
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(stdout);
+    fflush(stderr);
+    _exit(status);
+}
+
 // ---------------------------------------------------------------- OutFile
 bool OutFile::open(const char *path, bool gz)
 {
@@ -98,7 +107,7 @@ void OutFile::gpu_bgzf(const std::vector<std::string> &parts)
         pin_out = (unsigned char *)sk_bgzf_host_alloc(kGpuRun * 65536);
         if (!pin_text || !pin_out) {
             error("could not allocate pinned staging for the GPU deflate");
-            exit(EXIT_FAILURE);
+            fatal_exit(EXIT_FAILURE);
         }
     }
     WorkerPool &pool = WorkerPool::instance();
@@ -116,7 +125,7 @@ void OutFile::gpu_bgzf(const std::vector<std::string> &parts)
         const int rc = sk_bgzf_deflate(gpu_device, pin_text, sizes.data(), (uint32_t)nb, pin_out, csize.data());
         if (rc != SK_OK) { // no CPU fallback behind the GPU setting
             error(std::string("sk_bgzf_deflate failed: ") + sk_bgzf_last_error());
-            exit(EXIT_FAILURE);
+            fatal_exit(EXIT_FAILURE);
         }
         at[0] = 0;
         for (size_t b = 0; b < nb; ++b) {
@@ -283,7 +292,7 @@ int Abstract_Trimmer::open_device()
 void Abstract_Trimmer::ensure_device()
 {
     if (device_opener.joinable()) device_opener.join();
-    if (!devices_ok) exit(EXIT_FAILURE); // the opener has printed why
+    if (!devices_ok) fatal_exit(EXIT_FAILURE); // the opener has printed why
 }
 
 void Abstract_Trimmer::close_device()
@@ -313,7 +322,7 @@ void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bo
 {
     auto fail = [&](const char *what) {
         fprintf(stderr, "****Error: could not allocate pinned %s buffer: %s\n\n", what, sk_last_error(ctx));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     };
     if (bytes + 64 > s.cap_bytes || (need_seq && !s.seq)) {
         const size_t cap = std::max(s.cap_bytes, bytes + 64 + (bytes >> 3));
@@ -475,7 +484,7 @@ void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
     const int rc = sk_submit(ctx, dev_slot, &p, &b, s.cuts);
     if (rc != SK_OK) {
         fprintf(stderr, "****Error: device scan could not be started (%d): %s\n\n", rc, sk_last_error(ctx));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
 }
 
@@ -496,11 +505,11 @@ const cutsites *Abstract_Trimmer::wait_scan(int slot, const RawVec<FQEntry> &rea
         fprintf(stderr, "Quality string: %s\n", std::string(r.qual).c_str());
         fprintf(stderr, "Quality char: '%c'\n", (char)e.ch);
         fprintf(stderr, "Quality position: %d\n", (int)e.pos + 1);
-        exit(1);
+        fatal_exit(1);
     }
     if (rc != SK_OK) {
         fprintf(stderr, "****Error: device scan failed (%d): %s\n\n", rc, sk_last_error(ctx));
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     return reinterpret_cast<const cutsites *>(slots[(size_t)slot].cuts);
 }
@@ -538,7 +547,7 @@ int Abstract_Trimmer::recommended_batch_len_for(const char *path, unsigned long 
     if (stat(path, &st) != 0) {
         // the reference dies here with an uncaught std::filesystem error (abort)
         fprintf(stderr, "****Error: Could not open input file '%s'.\n\n", path);
-        exit(EXIT_FAILURE);
+        fatal_exit(EXIT_FAILURE);
     }
     const unsigned long long min_len = 20;
     const unsigned long long recommended = (unsigned long long)st.st_size / 8;

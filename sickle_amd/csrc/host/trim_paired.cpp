@@ -398,7 +398,7 @@ int Trim_Paired::trim_main()
             if (input_inter && pairs == all_pairs && (size_t)batch->n_lines() % 8 == 4) {
                 // unreachable (interleaved batches hold whole pairs), kept for the message
                 error("Reading interleaved pair: read1 loaded, but no read2 to load. Maybe it's not an interleaved file?");
-                exit(EXIT_FAILURE);
+                fatal_exit(EXIT_FAILURE);
             }
             w->reads.resize(2 * pairs);
             // record positions restart at 1 in every batch in PE (:309-310)

@@ -146,11 +146,13 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
 // LDS bytes per wave for the tiles of a ragged batch whose reads are at most `max_len` bytes
 // (0 = unknown): 64 reads + what a lane may read past its row, so that uniform 150 bp gets 10 KiB
 // (16 waves per CU); tiles that do not fit go to the general kernel.
-uint32_t rag_buf_bytes(uint64_t max_len)
+uint32_t rag_buf_bytes(uint64_t max_len, bool uniform)
 {
     if (max_len == 0) return SK_RAG_BUF_DEFAULT;
-    const uint64_t pitch = 16 * (((max_len + 15) >> 4) | 1); // == rag_pitch() of the kernels
-    uint64_t need = 64 * pitch + SK_TILE_SLACK;
+    // == rag_pitch<UNIFORM>() of the kernels
+    (void)uniform;
+    const uint64_t pitch = 16 * (((max_len + 15) >> 4) | 1);
+    uint64_t need = (64 * pitch + SK_TILE_SLACK + 15) & ~(uint64_t)15;
     if (need < 4096) need = 4096;
     if (need > SK_RAG_BUF_MAX) need = SK_RAG_BUF_MAX;
     return (uint32_t)need;
@@ -191,7 +193,7 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         const bool ragged = b->offsets || b->lengths;
         // b->stride of an `offsets` batch is the caller's hint of the longest read (0 = unknown); with
         // stride + lengths it bounds the reads; packed uniform batches: the read length is known
-        ar.buf_bytes = rag_buf_bytes(ragged ? b->stride : b->read_len);
+        ar.buf_bytes = rag_buf_bytes(ragged ? b->stride : b->read_len, !ragged);
         SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)
@@ -419,7 +421,7 @@ uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *ou
     // pass 2: runs are gathered into a class until it can fill the device a few times over; then the
     // next run of a different kind opens a new class (a class takes the widest stride and the wide
     // loop of its runs); a short last class joins the one before it
-    static const uint32_t min_tiles = [] { const char *e = getenv("SK_SEG_MIN_TILES"); return e ? (uint32_t)atoi(e) : 8192u; }();
+    static const uint32_t min_tiles = [] { const char *e = getenv("SK_SEG_MIN_TILES"); return e ? (uint32_t)atoi(e) : 65536u; }();
     std::vector<sk_seg_class> merged;
     auto join = [](sk_seg_class &m, const sk_seg_class &r) {
         m.n_tiles += r.n_tiles;

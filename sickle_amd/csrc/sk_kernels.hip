@@ -243,11 +243,25 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
 }
 
 // row pitch of the LDS image the re-striding loader builds for reads of up to `len` bytes.  The loader
-// moves 16 bytes per lane, so a multiple of 16; an ODD number of 16-byte units spreads the rows'
-// 8-byte reads over all banks two lanes to a bank pair (with 16-byte granules that is the best there
-// is; 4-byte granules give the conflict-free pitch of the strided layouts but cost four times the DMA
-// instructions, which measured slower: 3.2 against TB/s on packed 150 bp)
-__device__ __forceinline__ uint32_t rag_pitch(uint32_t len) { return 16u * (((len + 15u) >> 4) | 1u); }
+// moves 16 bytes per lane, so a multiple of 16, with an ODD number of 16-byte units: the rows' 8-byte
+// reads (matrix path) then fall two lanes to a bank pair and their 4-byte reads (vector-ALU path) four
+// lanes to a bank -- the best 16-byte granules allow.  Measured alternative for the vector-ALU path:
+// 4 bytes per lane and a pitch of 4 * odd has no bank conflicts (SQ_LDS_BANK_CONFLICT 67 % -> 0 of
+// the LDS cycles on a 75-301 bp mix) but four times the DMA instructions, and is slower: 0.59 against
+// 0.46 ms on that mix, 0.67 against 0.61 ms on ragged 150 bp.
+template <bool UNIFORM>
+__device__ __forceinline__ uint32_t rag_pitch(uint32_t len)
+{
+    return 16u * (((len + 15u) >> 4) | 1u);
+}
+
+// one LDS-DMA of the re-striding loader: 16 bytes per lane (uniform lengths) or 4
+template <bool WIDE>
+__device__ __forceinline__ void dma_piece(const uint8_t *g, uint8_t *l)
+{
+    if (WIDE) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, SK_DMA_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, SK_DMA_AUX);
+}
 
 // One tile = reads [64t, 64t+64) of a batch whose rows start at any byte address (`offsets`, or a
 // fixed stride that is not a multiple of 8, with or without `lengths`), as its lanes see it
@@ -290,7 +304,7 @@ __device__ __forceinline__ sk_rag_tile rag_probe(uint64_t t, int lane, const uin
 // the wave's LDS buffer.  sk_scan_wave_kernel asks the same question and takes the other tiles.
 __device__ __forceinline__ bool rag_tile_fits(const sk_rag_tile &g, uint32_t buf_bytes)
 {
-    return g.lmax <= SK_RAG_MAX_LEN && 64u * rag_pitch((uint32_t)g.lmax) + SK_TILE_SLACK <= buf_bytes;
+    return g.lmax <= SK_RAG_MAX_LEN && 64u * rag_pitch<false>((uint32_t)g.lmax) + SK_TILE_SLACK <= buf_bytes;
 }
 
 // end of the batch's bytes (exclusive), for the test above
@@ -435,7 +449,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         } else if (RAG && UNIFORM) {
             v.off = (tt << 6) * stride;
             v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
-            v.ts = rag_pitch(a.read_len);
+            v.ts = rag_pitch<true>(a.read_len);
             v.bytes = (v.rows - 1u) * stride + a.read_len;
             v.len = (int)a.read_len;
             v.r = (tt << 6) + lane;
@@ -444,7 +458,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             v.off = g.start;
             v.bytes = g.span;
             v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
-            v.ts = rag_pitch((uint32_t)g.lmax);
+            v.ts = rag_pitch<false>((uint32_t)g.lmax);
             v.len = g.len;
             v.rowoff = g.rowoff;
             v.r = (tt << 6) + lane;
@@ -467,12 +481,13 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         v.r = (uint64_t)out_index[(uint32_t)v.r + min((uint32_t)lane, v.rows - 1u)];
     };
 
-    // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, pitch/16) comes
-    // from the row's start + 16c.  Chunks beyond a row's end fetch what follows it in the batch (nobody
+    // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, chunks per row)
+    // comes from the row's start + c chunks.  Chunks beyond a row's end fetch what follows it in the batch (nobody
     // reads them); the clamp keeps those inside the tile (a row's last chunk may still reach up to 15
     // bytes past it).
     auto rag_dma = [&](const uint8_t *base, uint8_t *dst, const sk_tile_view &v) {
-        const uint32_t cpr = v.ts >> 4; // 16-byte chunks per image row == pieces per tile
+        constexpr uint32_t GRAN = 16u; // bytes per lane per DMA (see rag_pitch)
+        const uint32_t cpr = v.ts / GRAN;             // chunks per image row == pieces per tile
         const uint32_t qd = 64u / cpr, rd = 64u % cpr;
         uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
         const uint8_t *src = base + v.off;
@@ -481,19 +496,19 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             uint32_t ro;
             if (UNIFORM) ro = rr * stride;
             else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
-            const uint32_t so = min(ro + 16u * cc, lim);
-            // a chunk may reach up to 15 bytes past its tile: harmless inside the batch, but the last
-            // chunks of the batch's last tile(s) must not leave the caller's buffer -- those few lanes
-            // copy their bytes one by one instead
-            const bool inside = v.off + so + 16u <= batch_end;
+            const uint32_t so = min(ro + GRAN * cc, lim);
+            // a chunk may reach past its tile: harmless inside the batch, but the last chunks of the
+            // batch's last tile(s) must not leave the caller's buffer -- those few lanes copy their
+            // bytes one by one instead
+            const bool inside = v.off + so + GRAN <= batch_end;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inside) == 0, 1)) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + p * 1024u), 16, 0, SK_DMA_AUX);
+                dma_piece<true>(src + so, dst + p * (64u * GRAN));
             } else {
                 if (inside) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + p * 1024u), 16, 0, SK_DMA_AUX);
+                    dma_piece<true>(src + so, dst + p * (64u * GRAN));
                 } else {
-                    for (uint32_t j = 0; j < 16u && v.off + so + j < batch_end; ++j)
-                        dst[p * 1024u + (uint32_t)lane * 16u + j] = src[so + j];
+                    for (uint32_t j = 0; j < GRAN && v.off + so + j < batch_end; ++j)
+                        dst[p * (64u * GRAN) + (uint32_t)lane * GRAN + j] = src[so + j];
                 }
             }
             cc += rd;

@@ -80,3 +80,23 @@ def test_gzip_output_deflated_on_the_gpu(workdir):
         outs[tag] = open(o, "rb").read()
     assert gzip.decompress(outs["gpu"]) == outs["plain"] == gzip.decompress(outs["zlib"])
     assert len(outs["gpu"]) < 0.6 * len(outs["plain"]) and outs["gpu"][-28:] == outs["zlib"][-28:]  # both end with the BGZF marker block
+
+
+def test_config0_se_sanger_on_bundled_file(workdir):
+    """BASELINE configs[0] verbatim: `sickle se` on the reference's test/test.fastq, Sanger q=20 l=20.  Expected
+    output = file 1 of the reference's self-paired `pe` run with the same flags (its own `se` crashes)."""
+    rec = cu.e2e()["runs"]["se_equiv_selfpair_sanger"]
+    argv = rec["argv"]
+    assert argv[argv.index("-t") + 1] == "sanger" and "-q" not in argv and "-l" not in argv  # the defaults are 20 / 20
+    out = os.path.join(str(workdir), "config0.fastq")
+    pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", "{inputs}/test.fastq", "-t", "sanger", "-q", "20", "-l", "20", "-o", out])
+    assert pr.returncode == 0, pr.stderr
+    assert os.path.getsize(out) == rec["outputs"]["o1.fastq"]["size"]
+    # default -a (all host threads): the SE deal puts read k in queue (k+1) mod T, so compare as record sets ...
+    from fastq_util import parse_fastq
+    got = parse_fastq(open(out, "rb").read())
+    assert len(got) == 2500 and "FastQ records kept: 2500" in pr.stdout.decode()
+    # ... and byte for byte at -a 1
+    pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", "{inputs}/test.fastq", "-t", "sanger", "-q", "20", "-l", "20", "-o", out, "-a", "1"])
+    assert pr.returncode == 0, pr.stderr
+    assert cu.md5_file(out) == rec["outputs"]["o1.fastq"]["md5"]

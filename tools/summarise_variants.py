@@ -29,7 +29,7 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
         ent["trace"] = [{"name": r["Name"][:100], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in rows]
         tot = sum(float(r["AverageNs"]) * int(r["Calls"]) for r in rows)
         # a variant may take two kernels per scan (ragged: tile + general): time per scan = total / scans
-        scans = max(int(r["Calls"]) for r in rows) if rows else 0
+        scans = int(line.get("scans_in_run", 0)) or (max(int(r["Calls"]) for r in rows) if rows else 0)
         if scans:
             ent["trace_avg_ms_per_scan"] = tot / scans / 1e6
             ent["algorithmic_GBps_by_trace"] = line["algorithmic_bytes_per_launch"] / (tot / scans) if tot else None
@@ -48,7 +48,7 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
     ent["counters_per_kernel_dispatch"] = counters
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         # per scan = per dispatch x kernels per scan (the counters were averaged over every sk_scan dispatch)
-        kps = len(ent.get("trace", [])) or 1
+        kps = (sum(t["calls"] for t in ent.get("trace", [])) / scans) if ent.get("trace") and scans else 1
         fetch = counters["FETCH_SIZE"]["avg_per_dispatch"] * 1024 * 2 * kps
         write = counters["WRITE_SIZE"]["avg_per_dispatch"] * 1024 * kps
         ent["hbm_bytes_per_scan"] = {"read": fetch, "write": write, "total": fetch + write,
