@@ -79,7 +79,7 @@ def summary_block(stdout_text):
     return "\n".join(keep).strip("\n")
 
 
-def check_run(binary, tmp, name, rec):
+def check_run(binary, tmp, name, rec, summary=True):
     """Replays one golden run; returns nothing, asserts."""
     for o in rec["outputs"]:
         p = os.path.join(str(tmp), o)
@@ -92,6 +92,8 @@ def check_run(binary, tmp, name, rec):
         assert os.path.exists(p), (name, o)
         assert os.path.getsize(p) == meta["size"], (name, o, os.path.getsize(p), meta["size"])
         assert md5_file(p) == meta["md5"], (name, o)
+    if not summary:
+        return
     want = summary_block(rec["stdout"])
     got = summary_block(pr.stdout.decode("latin-1"))
     # the golden run had its own repo root and temp dir: compare with paths normalised

@@ -182,7 +182,80 @@ def write_synth_inputs(tmp):
     return made
 
 
+THREAD_ORDER_RUNS = {
+    # name: (kind, inputs, qualtype, extra flags, threads)
+    "pe_fr_illumina_a4": ("two", ("{inputs}/test.f.fastq", "{inputs}/test.r.fastq"), "illumina", [], 4),
+    "pe_fr_illumina_n_a3": ("two", ("{inputs}/test.f.fastq", "{inputs}/test.r.fastq"), "illumina", ["-n"], 3),
+    "pe_syn_fr_sanger_a4": ("two", ("{tmp}/syn_R1.fastq", "{tmp}/syn_R2.fastq"), "sanger", [], 4),
+    "pe_syn_fr_sanger_a16": ("two", ("{tmp}/syn_R1.fastq", "{tmp}/syn_R2.fastq"), "sanger", [], 16),
+    "pe_inter_illumina_a5": ("inter", ("{inputs}/test.fastq",), "illumina", [], 5),
+    "pe_syn_mixed_inter_illumina_n_a7": ("inter", ("{tmp}/syn_mixed_inter.fastq",), "illumina", ["-n"], 7),
+}
+
+
+def thread_order_goldens(tmp):
+    """`sickle pe -a T`, T > 1.  The reference's per-batch output threads race each other for the files
+    (src/trim_paired.cpp:445-458), so its BATCHES land in any order -- but inside a batch the order is fixed:
+    pair k in queue k mod T, queues written in turn.  For each run: the expected per-batch chunks are derived
+    (fastq_util: the restated batch-cut rule + queue order, cuts from the compiled reference's sliding_window),
+    every reference run's three files must be a permutation of exactly those chunks, and what is recorded is
+    the md5 of the chunks in batch order -- which is what this repo's CLI writes."""
+    from fastq_util import (expected_pe_outputs, file_lines, is_permutation_of_chunks, reference_batch_len,
+                            reference_batches)
+    out = {}
+    for name, (kind, inputs, qt, extra, threads) in THREAD_ORDER_RUNS.items():
+        paths = [a.format(tmp=tmp, inputs=INPUTS) for a in inputs]
+        datas = [open(p, "rb").read() for p in paths]
+        blen = reference_batch_len(len(datas[0]), 512, paired=True)
+        inter = kind == "inter"
+        b1 = reference_batches(file_lines(datas[0]), blen, 8 if inter else 4)
+        b2 = None if inter else reference_batches(file_lines(datas[1]), blen, 4)
+        p = ob.make_params(qt, 20, 20, False, "-n" in extra)
+        cuts = []
+        for d in datas:
+            recs = parse_fastq(d)
+            seq, qual, offsets = pack_records(recs)
+            cuts.append(ob.ref_trim_batch(p, qual, seq, offsets=offsets))
+        chunks = expected_pe_outputs(b1, b2, lambda f, r: cuts[f][r], threads, interleaved=inter)
+        assert len(chunks) > 3, (name, "needs several batches to mean anything")
+        if inter:
+            argv = ["pe", "-c", inputs[0], "-m", "{tmp}/om.fastq", "-s", "{tmp}/os.fastq", "-t", qt, "-a", str(threads)] + extra
+            files = {"om.fastq": 0, "os.fastq": 2}
+        else:
+            argv = ["pe", "-f", inputs[0], "-r", inputs[1], "-o", "{tmp}/o1.fastq", "-p", "{tmp}/o2.fastq", "-s", "{tmp}/os.fastq",
+                    "-t", qt, "-a", str(threads)] + extra
+            files = {"o1.fastq": 0, "o2.fastq": 1, "os.fastq": 2}
+        orders = set()
+        for attempt in range(4):
+            for o in files:
+                if os.path.exists(os.path.join(tmp, o)):
+                    os.remove(os.path.join(tmp, o))
+            pr = subprocess.run([ob.REF_BIN] + [a.format(tmp=tmp, inputs=INPUTS) for a in argv], capture_output=True, timeout=600)
+            assert pr.returncode == 0, pr.stderr[-300:]
+            for o, idx in files.items():
+                data = open(os.path.join(tmp, o), "rb").read()
+                assert is_permutation_of_chunks(data, [c[idx] for c in chunks]), \
+                    (name, o, "the reference's output is not a permutation of the derived per-batch chunks")
+            orders.add(md5(os.path.join(tmp, list(files)[0])))
+        rec = {"argv": argv, "rc": 0, "batches": len(chunks), "threads": threads, "outputs": {},
+               "distinct_reference_orders_seen": len(orders)}
+        for o, idx in files.items():
+            whole = b"".join(c[idx] for c in chunks)
+            rec["outputs"][o] = {"md5": hashlib.md5(whole).hexdigest(), "size": len(whole)}
+        out[name] = rec
+        print(name, "batches", len(chunks), "reference orders seen", len(orders), {k: v["size"] for k, v in rec["outputs"].items()})
+    return out
+
+
 def main():
+    if "--only-thread-order" in sys.argv:  # adds / refreshes e2e.json["thread_order"], leaves the rest alone
+        assert ob.have_ref()
+        e2e = json.load(open(os.path.join(HERE, "e2e.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            assert write_synth_inputs(tmp) == e2e["synth_inputs_md5"]
+            e2e["thread_order"] = thread_order_goldens(tmp)
+        json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+        return
     assert ob.have_ref(), "build oracle/_ref first (make -C oracle) in the container with /root/reference"
     os.makedirs(INPUTS, exist_ok=True)
     for f in ("test.fastq", "test.f.fastq", "test.r.fastq", "problem1.fastq"):
@@ -261,6 +334,7 @@ def main():
                     os.remove(os.path.join(tmp, o))
             e2e["runs"][name] = run_ref_pe(tmp, argv, outs)
             print(name, "rc", e2e["runs"][name]["rc"], {k: v["size"] for k, v in e2e["runs"][name]["outputs"].items()})
+        e2e["thread_order"] = thread_order_goldens(tmp)
         json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
 
 

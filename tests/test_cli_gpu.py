@@ -100,3 +100,40 @@ def test_config0_se_sanger_on_bundled_file(workdir):
     pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", "{inputs}/test.fastq", "-t", "sanger", "-q", "20", "-l", "20", "-o", out, "-a", "1"])
     assert pr.returncode == 0, pr.stderr
     assert cu.md5_file(out) == rec["outputs"]["o1.fastq"]["md5"]
+
+
+@pytest.mark.parametrize("name", sorted(cu.e2e()["thread_order"].keys()))
+def test_thread_order_goldens_on_gpu(workdir, name):
+    """`sickle pe -a T` with T > 1 through the product binary: the reference's per-batch chunks in batch order,
+    byte for byte (tests/golden/make_golden.py: thread_order_goldens)."""
+    cu.check_run(cu.PRODUCT_BIN, workdir, name, dict(cu.e2e()["thread_order"][name], stdout=""), summary=False)
+
+
+def test_se_thread_order_on_gpu(workdir):
+    """`sickle se -a 4` and the default -a (every host thread) through the product binary: read k of a batch in
+    queue (k+1) mod T, derived from the oracle's cuts and the restated batch-cut rule."""
+    import os as _os
+    from test_cli_host import derived_expectation
+    src = _os.path.join(cu.INPUTS, "test.fastq")
+    out = _os.path.join(str(workdir), "se_gpu_T.fastq")
+    for threads in (4, None):
+        argv = ["se", "-f", src, "-t", "illumina", "-o", out] + (["-a", str(threads)] if threads else [])
+        pr = cu.run_cli(cu.PRODUCT_BIN, workdir, argv)
+        assert pr.returncode == 0, pr.stderr
+        T = threads or max(1, _os.cpu_count() or 1)  # default: std::thread::hardware_concurrency()
+        assert open(out, "rb").read() == derived_expectation([src], "illumina", T, single=True), threads
+
+
+def test_malformed_record_in_a_later_batch_exits_1_on_gpu(workdir):
+    """A malformed record far into the file: validate() fires on the reader thread while the main thread is in
+    sk_submit / sk_wait for earlier batches -- the process must leave with the reference's message and status 1
+    (fatal_exit: no static destructors under live GPU work)."""
+    from sickle_amd import synth
+    seq, qual = synth.make_reads(9, 60_000, 150, "sanger")
+    good = synth.fastq_bytes(seq, qual)
+    path = os.path.join(str(workdir), "late_bad.fastq")
+    open(path, "wb").write(good + b"@broken\nACGT\n+\nIII\n" + synth.fastq_bytes(seq[:1000], qual[:1000], start=70_000))
+    for threads in ("1", "8"):
+        pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", path, "-t", "sanger", "-o", "{tmp}/late_bad_out.fastq", "-a", threads])
+        assert pr.returncode == 1, (pr.returncode, pr.stderr[-300:])
+        assert b"[ERROR] Sequence and quality lines have different lengths:" in pr.stderr

@@ -86,30 +86,55 @@ def test_se_thread_count_sets_record_order(hostcheck, workdir):
     assert r4[0][0] == recs[first][0]
 
 
-def test_pe_thread_order_matches_reference_a4(hostcheck, workdir):
-    """The same run at -a 4 through the reference binary, where it is available (build container).
-    The reference's per-batch output threads race each other for the file (they are only joined at
-    the end, src/trim_paired.cpp:445-458), so its batch order varies from run to run; the queue-major
-    order INSIDE a batch does not.  Accept a byte-identical match with any of a few reference runs."""
-    if not ob.have_ref():
-        pytest.skip("compiled reference not present")
+@pytest.mark.parametrize("name", sorted(cu.e2e()["thread_order"].keys()))
+def test_pe_thread_order_goldens(hostcheck, workdir, name):
+    """`sickle pe -a T`, T > 1, byte for byte.  The goldens are the per-batch chunks of the reference in batch
+    order: make_golden.py derives them (restated batch-cut rule + queue order) and checks that every run of the
+    compiled reference is a permutation of exactly those chunks (its batches race for the files; the order inside
+    a batch does not).  No multiset fallback."""
+    cu.check_run(hostcheck, workdir, name, dict(cu.e2e()["thread_order"][name], stdout=""), summary=False)
 
-    def run(binary, tag):
-        d = os.path.join(str(workdir), "a4_" + tag)
-        os.makedirs(d, exist_ok=True)
-        pr = subprocess.run([binary, "pe", "-f", os.path.join(cu.INPUTS, "test.f.fastq"), "-r",
-                             os.path.join(cu.INPUTS, "test.r.fastq"), "-t", "illumina", "-a", "4", "-o", d + "/o1",
-                             "-p", d + "/o2", "-s", d + "/os"], capture_output=True, timeout=300)
-        assert pr.returncode == 0
-        return [cu.md5_file(d + "/" + f) for f in ("o1", "o2", "os")]
 
-    new = run(hostcheck, "new")
-    refs = [run(ob.REF_BIN, "ref%d" % i) for i in range(6)]
-    if new not in refs:  # every reference run lost its race this time: fall back to the record multiset
-        for f in ("o1", "o2", "os"):
-            a = parse_fastq(open(os.path.join(str(workdir), "a4_new", f), "rb").read())
-            b = parse_fastq(open(os.path.join(str(workdir), "a4_ref0", f), "rb").read())
-            assert sorted(a) == sorted(b)
+def derived_expectation(paths, qt, threads, interleaved=False, single=False):
+    from fastq_util import (expected_pe_outputs, expected_se_output, file_lines, reference_batch_len, reference_batches)
+    datas = [open(p, "rb").read() for p in paths]
+    blen = reference_batch_len(len(datas[0]), 512, paired=not single)
+    cuts = []
+    for d in datas:
+        recs = parse_fastq(d)
+        seq, qual, offsets = pack_records(recs)
+        c, err = ob.oracle_trim_batch(ob.make_params(qt), qual, seq, offsets=offsets)
+        assert err is None
+        cuts.append(c)
+    b1 = reference_batches(file_lines(datas[0]), blen, 8 if interleaved else 4)
+    if single:
+        return b"".join(expected_se_output(b1, lambda f, r: cuts[f][r], threads))
+    b2 = None if interleaved else reference_batches(file_lines(datas[1]), blen, 4)
+    chunks = expected_pe_outputs(b1, b2, lambda f, r: cuts[f][r], threads, interleaved=interleaved)
+    return [b"".join(c[i] for c in chunks) for i in range(3)]
+
+
+@pytest.mark.parametrize("threads,host_threads", [(2, None), (3, "3"), (4, "5"), (7, "2"), (64, "3"), (5000, None)])
+def test_thread_order_derived_for_any_T(hostcheck, workdir, threads, host_threads):
+    """Queue-major order for thread counts that do not divide the batch, that exceed the reads of a batch
+    (T = 5000 > 312 pairs per batch) and with the host pool cut so that its part boundaries fall inside queues
+    (SICKLE_HOST_THREADS): SE (read k -> queue (k+1) mod T) and two-file PE (pair k -> queue k mod T) against
+    the expectation derived from the oracle's cuts and the restated batch-cut rule."""
+    env = {"SICKLE_HOST_THREADS": host_threads} if host_threads else None
+    d = str(workdir)
+    src = os.path.join(cu.INPUTS, "test.fastq")
+    out = os.path.join(d, "se_T.fastq")
+    pr = cu.run_cli(hostcheck, workdir, ["se", "-f", src, "-t", "illumina", "-o", out, "-a", str(threads)], env=env)
+    assert pr.returncode == 0, pr.stderr
+    assert open(out, "rb").read() == derived_expectation([src], "illumina", threads, single=True)
+    f, r = os.path.join(cu.INPUTS, "test.f.fastq"), os.path.join(cu.INPUTS, "test.r.fastq")
+    outs = [os.path.join(d, "pe_T_%d" % i) for i in range(3)]
+    pr = cu.run_cli(hostcheck, workdir, ["pe", "-f", f, "-r", r, "-t", "illumina", "-o", outs[0], "-p", outs[1], "-s", outs[2],
+                                         "-a", str(threads)], env=env)
+    assert pr.returncode == 0, pr.stderr
+    want = derived_expectation([f, r], "illumina", threads)
+    for o, w in zip(outs, want):
+        assert open(o, "rb").read() == w, (threads, o)
 
 
 def test_usage_and_argument_errors(hostcheck, workdir):
