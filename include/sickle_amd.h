@@ -157,9 +157,10 @@ void sk_host_free(sk_ctx *ctx, void *p);
  * Device-resident batch: every pointer in *batch and `out` is a DEVICE pointer.  Enqueues
  * the scan on `hip_stream` (a hipStream_t; NULL = HIP's default stream, so it is ordered after
  * the work the caller queued there) and
- * returns without waiting.  out[r] is written for every read.  Range errors of all scans
- * enqueued since the last sk_scan_device_finish accumulate in one device word (lowest read
- * index wins); nothing but the kernel is enqueued here.
+ * returns without waiting.  out[r] is written for every read.  Range errors of the scans enqueued
+ * on one stream since that stream's last sk_scan_device_finish accumulate in one device word per
+ * stream (lowest read index wins), so scans on different streams of one context do not steal each
+ * other's errors; nothing but the kernel(s) is enqueued here.  One host thread per context at a time.
  */
 int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *batch,
                          sk_cut *out, void *hip_stream);

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -54,13 +56,23 @@ struct sk_ctx {
     int device = 0;
     int cu_count = 256;
     hipStream_t compute = nullptr, copy = nullptr;
-    unsigned long long *d_err = nullptr; // error word of the device-resident path
+    unsigned long long *d_err = nullptr; // error word of the device-resident path on the NULL stream
     unsigned long long *h_err = nullptr;
+    // ... and one per other stream the caller scans on: errors of scans enqueued on different streams do
+    // not meet in one word (each sk_scan_device_finish reports what ITS stream's scans found)
+    struct ErrWord {
+        unsigned long long *d = nullptr, *h = nullptr;
+    };
+    std::map<hipStream_t, ErrWord> stream_err;
+    std::mutex stream_err_lock;
     std::vector<Slot> slots;
     char last_error[512] = {0};
 };
 
 namespace {
+
+// the error word (device, pinned host copy) of the device-resident scans on `stream`
+int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h);
 
 void set_error(sk_ctx *ctx, const char *fmt, ...)
 {
@@ -201,6 +213,27 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
     } else {
         SK_HIP(ctx, sk_launch_team(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->read_len, ctx->cu_count, stream));
     }
+    return SK_OK;
+}
+
+int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h)
+{
+    if (stream == nullptr) {
+        *d = ctx->d_err;
+        *h = ctx->h_err;
+        return SK_OK;
+    }
+    std::lock_guard<std::mutex> lock(ctx->stream_err_lock);
+    sk_ctx::ErrWord &w = ctx->stream_err[stream];
+    if (!w.d) {
+        SK_HIP(ctx, hipSetDevice(ctx->device));
+        SK_HIP(ctx, hipMalloc(&w.d, sizeof(unsigned long long)));
+        SK_HIP(ctx, hipMemset(w.d, 0xff, sizeof(unsigned long long))); // synchronous: done before any scan is enqueued
+        SK_HIP(ctx, hipHostMalloc(&w.h, sizeof(unsigned long long), hipHostMallocDefault));
+        *w.h = kNoError;
+    }
+    *d = w.d;
+    *h = w.h;
     return SK_OK;
 }
 
@@ -359,6 +392,10 @@ void sk_destroy(sk_ctx *ctx)
     }
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    for (auto &kv : ctx->stream_err) {
+        if (kv.second.d) (void)hipFree(kv.second.d);
+        if (kv.second.h) (void)hipHostFree(kv.second.h);
+    }
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     delete ctx;
@@ -485,18 +522,24 @@ int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *b
     // NULL is HIP's default (null) stream, like everywhere else in HIP: ordered after whatever the
     // caller queued there (e.g. the kernels that produced the batch)
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), ctx->d_err, stream);
+    unsigned long long *d_err, *h_err;
+    rc = err_word_of(ctx, stream, &d_err, &h_err);
+    if (rc != SK_OK) return rc;
+    return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), d_err, stream);
 }
 
 int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err)
 {
     if (!ctx) return SK_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    SK_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    int rc = reset_error_word(ctx, ctx->d_err, stream);
+    unsigned long long *d_err, *h_err;
+    int rc = err_word_of(ctx, stream, &d_err, &h_err);
+    if (rc != SK_OK) return rc;
+    SK_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    rc = reset_error_word(ctx, d_err, stream);
     if (rc != SK_OK) return rc;
     SK_HIP(ctx, hipStreamSynchronize(stream));
-    return decode_error(*ctx->h_err, err);
+    return decode_error(*h_err, err);
 }
 
 int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *batch, sk_cut *out)

@@ -97,6 +97,11 @@ int sk_bgzf_deflate(int device, const uint8_t *text, const uint32_t *sizes, uint
     if (device < 0 || device >= 16 || (n_blocks && (!text || !sizes || !out || !out_sizes))) return SK_EINVAL;
     if (n_blocks == 0) return SK_OK;
     std::lock_guard<std::mutex> lk(g_lock); // callers are the writer threads of the output files: one batch at a time
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        if (sizes[b] > SKD_BLOCK_MAX) { // the kernel's token scratch and LDS tables are sized for one BGZF block
+            snprintf(g_error, sizeof g_error, "sizes[%u] = %u exceeds the block size %u", b, sizes[b], (unsigned)SKD_BLOCK_MAX);
+            return SK_EINVAL;
+        }
     DeflateState &s = g_state[device];
     SKD_HIP(hipSetDevice(device));
     if (!s.ready) {

@@ -36,6 +36,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "sk_device.h"
 
 namespace {
@@ -1357,6 +1361,33 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// The dynamic-LDS ceiling of a kernel is a property of (device, function) in the HIP runtime; it is
+// raised ONCE per pair to the CU's 160 KiB and every launch then passes its own size.  (Setting it per
+// launch to that launch's size raced between host threads scanning batches of different strides on one
+// device: A sets 80 KiB, B sets 10 KiB, A's launch fails.)  Also caches the kernel's register count.
+struct kernel_facts {
+    hipError_t status = hipSuccess;
+    int regs = 0;
+};
+template <typename K>
+kernel_facts prepare_kernel(K kern)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, kernel_facts> seen;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const void *fn = reinterpret_cast<const void *>(kern);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find({device, fn});
+    if (it != seen.end()) return it->second;
+    kernel_facts f;
+    f.status = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_PER_CU);
+    hipFuncAttributes fa;
+    if (f.status == hipSuccess && hipFuncGetAttributes(&fa, fn) == hipSuccess) f.regs = fa.numRegs;
+    if (f.status == hipSuccess) seen[{device, fn}] = f; // a failure is retried by the next launch
+    return f;
+}
+
 int tile_nbuf_default()
 {
     // diagnostic override (tools/ablate.py, A/B runs): SK_TILE_NBUF=1|2
@@ -1388,22 +1419,16 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
     if (lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
     if (per_cu > 16) per_cu = 16;
+    const kernel_facts facts = prepare_kernel(kern);
+    if (facts.status != hipSuccess) return facts.status;
     if (by_registers) {
         // the staged kernels are bounded by their registers, not by LDS (the grid is persistent, so
         // workgroups beyond what fits would only run as a second round): waves per SIMD = the 512
         // registers of a lane's file over the kernel's count (allocated in eights), four SIMDs
-        static thread_local const void *asked = nullptr;
-        static thread_local int fits = 0;
-        if (asked != reinterpret_cast<const void *>(kern)) {
-            hipFuncAttributes fa;
-            int regs = 0;
-            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs = fa.numRegs;
-            if (regs <= 0) regs = 160;
-            asked = reinterpret_cast<const void *>(kern);
-            fits = 4 * (512 / ((regs + 7) & ~7));
-            if (fits < 4) fits = 4;
-            if (getenv("SK_DEBUG_LAUNCH")) fprintf(stderr, "[sk] staged kernel: %d registers -> %d workgroups per CU\n", regs, fits);
-        }
+        const int regs = facts.regs > 0 ? facts.regs : 160;
+        int fits = 4 * (512 / ((regs + 7) & ~7));
+        if (fits < 4) fits = 4;
+        if (getenv("SK_DEBUG_LAUNCH")) fprintf(stderr, "[sk] staged kernel: %d registers -> %d workgroups per CU\n", regs, fits);
         if (per_cu > fits) per_cu = fits;
     }
     if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
@@ -1411,9 +1436,6 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
     uint64_t grid = (uint64_t)cu_count * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, lengths, out, errword, *a,
                        (const sk_tile_dev *)nullptr, (const uint32_t *)nullptr);
     return hipGetLastError();
@@ -1498,9 +1520,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
         as.buf_bytes = lds_bytes;
         as.n_tiles = k.n_tiles;
         auto launch = [&](auto kern) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return e;
+            const kernel_facts facts = prepare_kernel(kern);
+            if (facts.status != hipSuccess) return facts.status;
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq,
                                (const uint32_t *)nullptr, out, errword, as, tiles + k.first_tile, out_index);
             return hipGetLastError();
@@ -1532,9 +1553,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return hipSuccess;
     auto launch = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
+        const kernel_facts facts = prepare_kernel(kern);
+        if (facts.status != hipSuccess) return facts.status;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
                            errword, *a);
         return hipGetLastError();
@@ -1605,9 +1625,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const
     if (grid > work) grid = work;
     if (grid == 0) return hipSuccess;
     auto launch = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
+        const kernel_facts facts = prepare_kernel(kern);
+        if (facts.status != hipSuccess) return facts.status;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
                            errword, at);
         return hipGetLastError();

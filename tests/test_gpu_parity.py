@@ -392,3 +392,31 @@ def test_register_staged_tiles(sk_ctx):
     with pytest.raises(capi.RangeError) as ei:
         sk_ctx.trim_batch(p, qs.reshape(-1), stride=stride, read_len=L, n_reads=n)
     assert (ei.value.read, ei.value.pos, ei.value.ch) == (n - 3, 5, 20)
+
+
+def test_streams_keep_their_own_range_errors(sk_ctx):
+    """Device-resident scans enqueued on two streams of one context: each sk_scan_device_finish reports what the
+    scans of ITS stream found, whatever finishes first."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 4096
+    p = capi.make_params("sanger")
+    bufs = []
+    for bad_read in (10, 700, None):
+        q = torch.full((n, 152), 75, dtype=torch.uint8, device=dev)
+        if bad_read is not None:
+            q[bad_read, 7] = 20
+        bufs.append((q, torch.empty((n, 2), dtype=torch.int32, device=dev)))
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    sk_ctx.scan_device_async(p, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), n, stride=152, read_len=150, stream=s1.cuda_stream)
+    sk_ctx.scan_device_async(p, bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), n, stride=152, read_len=150, stream=s2.cuda_stream)
+    with pytest.raises(capi.RangeError) as e2:
+        sk_ctx.scan_device_finish(s2.cuda_stream)
+    assert (e2.value.read, e2.value.pos, e2.value.ch) == (700, 7, 20)
+    with pytest.raises(capi.RangeError) as e1:
+        sk_ctx.scan_device_finish(s1.cuda_stream)
+    assert (e1.value.read, e1.value.pos, e1.value.ch) == (10, 7, 20)
+    sk_ctx.scan_device_async(p, bufs[2][0].data_ptr(), bufs[2][1].data_ptr(), n, stride=152, read_len=150, stream=s2.cuda_stream)
+    sk_ctx.scan_device_finish(s2.cuda_stream)  # clean: the earlier error was consumed
+    assert bool((bufs[2][1][:, 1] == 150).all())
