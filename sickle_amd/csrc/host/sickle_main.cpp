@@ -46,15 +46,17 @@ int main(int argc, char *argv[])
     } else if (strcmp(argv[1], "--help") == 0) {
         main_usage(EXIT_SUCCESS);
     } else if (strcmp(argv[1], "pe") == 0) {
-        Trim_Paired trimmer;
+        sickle_leave_fast = true;
+        static Trim_Paired trimmer; // static: not destroyed on the way out (fatal_exit does not unwind)
         retval = trimmer.parse_args(argc, argv);
         if (retval != 0) return retval;
         retval = trimmer.trim_main();
     } else {
-        Trim_Single trimmer;
+        sickle_leave_fast = true;
+        static Trim_Single trimmer;
         retval = trimmer.parse_args(argc, argv);
         if (retval != 0) return retval;
         retval = trimmer.trim_main();
     }
-    return retval;
+    fatal_exit(retval); // outputs are closed; everything else goes with the process (sickle.h)
 }

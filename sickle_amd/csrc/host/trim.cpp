@@ -29,6 +29,8 @@ void msg(const char *content)
 }
 void msg(const std::string &content) { msg(content.c_str()); }
 
+bool sickle_leave_fast = false;
+
 void fatal_exit(int status)
 {
     std::cout.flush();

@@ -227,6 +227,11 @@ int Trim_Paired::init_streams()
 
 void Trim_Paired::close_streams()
 {
+    outfile_single.close();
+    outfile.close();
+    outfile2.close();
+    outfile_interleaved.close();
+    if (sickle_leave_fast) return; // see sickle.h
     if (input_inter) {
         delete input_inter;
     } else {
@@ -234,10 +239,6 @@ void Trim_Paired::close_streams()
         delete input2;
     }
     input = input2 = input_inter = nullptr;
-    outfile_single.close();
-    outfile.close();
-    outfile2.close();
-    outfile_interleaved.close();
     close_device();
 }
 

@@ -161,9 +161,10 @@ int Trim_Single::init_streams()
 
 void Trim_Single::close_streams()
 {
+    outfile.close();
+    if (sickle_leave_fast) return; // see sickle.h
     delete input;
     input = nullptr;
-    outfile.close();
     close_device();
 }
 
