@@ -66,6 +66,7 @@ struct sk_ctx {
     std::map<hipStream_t, ErrWord> stream_err;
     std::mutex stream_err_lock;
     std::vector<Slot> slots;
+    unsigned long long scan_counter = 0;
     char last_error[512] = {0};
 };
 
@@ -150,6 +151,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
     a->tile_order = order;
     a->buf_bytes = 0;
+    a->scan_id = 0;
     a->team_rbuf = 0;
     a->team_maxlen = 0;
     return SK_OK;
@@ -203,6 +205,9 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
     } else if (path == 5) {
         sk_scan_args ar = *a;
         const bool ragged = b->offsets || b->lengths;
+        // the scans of a context are numbered upwards: the tile kernel leaves the number in the word after
+        // the error word when it skips a tile, the general kernel returns at once if it does not find it
+        ar.scan_id = ++ctx->scan_counter;
         // b->stride of an `offsets` batch is the caller's hint of the longest read (0 = unknown); with
         // stride + lengths it bounds the reads; packed uniform batches: the read length is known
         ar.buf_bytes = rag_buf_bytes(ragged ? b->stride : b->read_len, !ragged);
@@ -227,8 +232,9 @@ int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigne
     sk_ctx::ErrWord &w = ctx->stream_err[stream];
     if (!w.d) {
         SK_HIP(ctx, hipSetDevice(ctx->device));
-        SK_HIP(ctx, hipMalloc(&w.d, sizeof(unsigned long long)));
+        SK_HIP(ctx, hipMalloc(&w.d, 2 * sizeof(unsigned long long)));
         SK_HIP(ctx, hipMemset(w.d, 0xff, sizeof(unsigned long long))); // synchronous: done before any scan is enqueued
+        SK_HIP(ctx, hipMemset(w.d + 1, 0, sizeof(unsigned long long)));
         SK_HIP(ctx, hipHostMalloc(&w.h, sizeof(unsigned long long), hipHostMallocDefault));
         *w.h = kNoError;
     }
@@ -354,14 +360,16 @@ int sk_create(int device, int slots, sk_ctx **out)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    SK_TRY(hipMalloc(&ctx->d_err, sizeof(unsigned long long)));
+    SK_TRY(hipMalloc(&ctx->d_err, 2 * sizeof(unsigned long long)));
     SK_TRY(hipMemset(ctx->d_err, 0xff, sizeof(unsigned long long)));
+    SK_TRY(hipMemset(ctx->d_err + 1, 0, sizeof(unsigned long long))); // the hand-over word (see enqueue_scan)
     SK_TRY(hipHostMalloc(&ctx->h_err, sizeof(unsigned long long), hipHostMallocDefault));
     *ctx->h_err = kNoError;
     ctx->slots.resize((size_t)slots);
     for (Slot &s : ctx->slots) {
-        SK_TRY(hipMalloc(&s.d_err, sizeof(unsigned long long)));
+        SK_TRY(hipMalloc(&s.d_err, 2 * sizeof(unsigned long long)));
         SK_TRY(hipMemset(s.d_err, 0xff, sizeof(unsigned long long)));
+        SK_TRY(hipMemset(s.d_err + 1, 0, sizeof(unsigned long long)));
         SK_TRY(hipHostMalloc(&s.h_err, sizeof(unsigned long long), hipHostMallocDefault));
         SK_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         SK_TRY(hipEventCreateWithFlags(&s.finished, hipEventDisableTiming));

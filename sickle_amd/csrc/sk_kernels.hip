@@ -25,7 +25,7 @@
 //                         their rows 4 windows per dword with byte-parallel arithmetic
 //                         (v_alignbyte, signed byte differences, v_dot4_i32_i8, v_alignbit).
 //                         Range check: two v_sad_u8 per dword.
-//   sk_scan_wave_kernel   any layout (ragged offsets, odd strides, long reads).  One
+//   sk_scan_team_kernel   any layout (ragged offsets, odd strides, long reads).  One
 //                         WAVEFRONT per read; each lane owns a contiguous run of windows,
 //                         seeds its window sum directly and rolls it in a register; the
 //                         per-lane first-hits are combined with wave min-reductions.
@@ -91,17 +91,60 @@ __device__ __forceinline__ uint32_t ffbl_or_none(uint32_t x)
 }
 constexpr uint32_t NONE = 0xffffffffu;
 
+// ---- reductions on the data-parallel-primitive path (v_*_dpp: a lane reads its neighbour's register in the
+// same instruction, no LDS crossbar, no wait): four steps leave the result of each ROW of 16 lanes in all of
+// its lanes; the four rows are then combined through scalar registers (v_readlane + s_min/s_max).
+constexpr int DPP_QUAD_SWAP1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+template <int CTRL>
+__device__ __forceinline__ int dpp_peer(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int row_min(int v) // min over the 16-lane row, in every lane of the row
+{
+    v = min(v, dpp_peer<DPP_QUAD_SWAP1>(v));
+    v = min(v, dpp_peer<DPP_QUAD_SWAP2>(v));
+    v = min(v, dpp_peer<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_peer<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ int row_max(int v)
+{
+    v = max(v, dpp_peer<DPP_QUAD_SWAP1>(v));
+    v = max(v, dpp_peer<DPP_QUAD_SWAP2>(v));
+    v = max(v, dpp_peer<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dpp_peer<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_or(uint32_t v)
+{
+    v |= (uint32_t)dpp_peer<DPP_QUAD_SWAP1>((int)v);
+    v |= (uint32_t)dpp_peer<DPP_QUAD_SWAP2>((int)v);
+    v |= (uint32_t)dpp_peer<DPP_ROW_HALF_MIRROR>((int)v);
+    v |= (uint32_t)dpp_peer<DPP_ROW_MIRROR>((int)v);
+    return v;
+}
+// wave-wide: one value per wave, in scalar registers
 __device__ __forceinline__ int wave_min(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = row_min(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = row_max(v);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v = row_or(v);
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+                      __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
 }
 
 __device__ __forceinline__ void report_error(unsigned long long *errword, uint64_t read, int pos, int ch)
@@ -300,12 +343,12 @@ __device__ __forceinline__ sk_rag_tile rag_probe(uint64_t t, int lane, const uin
     const bool ok = r < a.n_reads && o >= g.start && e >= o && e <= end;
     g.rowoff = ok ? (uint32_t)(o - g.start) : 0u;
     g.len = ok ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
-    g.lmax = __builtin_amdgcn_readfirstlane(wave_max(g.len));
+    g.lmax = wave_max(g.len);
     return g;
 }
 
 // Is the tile sk_scan_tile_any_kernel's?  Its re-strided image (64 rows at rag_pitch(lmax)) must fit
-// the wave's LDS buffer.  sk_scan_wave_kernel asks the same question and takes the other tiles.
+// the wave's LDS buffer.  sk_scan_team_kernel asks the same question and takes the other tiles.
 __device__ __forceinline__ bool rag_tile_fits(const sk_rag_tile &g, uint32_t buf_bytes)
 {
     return g.lmax <= SK_RAG_MAX_LEN && 64u * rag_pitch<false>((uint32_t)g.lmax) + SK_TILE_SLACK <= buf_bytes;
@@ -328,7 +371,8 @@ struct sk_tile_view {
     int len;         // read length: one value when UNIFORM, per lane otherwise (0 past the end)
     uint64_t r;      // per lane: where this lane's cut goes in out[]
     uint32_t rowoff; // ragged: per lane, where the lane's read starts, relative to off
-    bool take;       // rows at any address: false = left to sk_scan_wave_kernel
+    bool take;       // rows at any address: false = left to sk_scan_team_kernel
+    bool uni;        // ragged: the tile's 64 reads have one length (their rows are then len apart)
 };
 
 } // namespace
@@ -342,7 +386,7 @@ struct sk_tile_view {
 // (tools/probes/restride_probe.hip): the re-striding DMA streams at the rate of the plain one
 // (6.4 TB/s), whereas reading unaligned rows out of LDS costs 8x per ds_read.  Uniform lengths keep
 // the matrix path; per-lane lengths walk the vector-ALU path.  A tile whose image does not fit the
-// wave's buffer (long reads) is left to sk_scan_wave_kernel.
+// wave's buffer (long reads) is left to sk_scan_team_kernel.
 template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
@@ -351,8 +395,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                   const uint32_t *__restrict__ out_index, const uint64_t *__restrict__ offsets)
 {
     static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
-    static_assert(!RAG || UNIFORM || !MFMA, "ragged batches walk the vector-ALU path");
-    static_assert(!MFMA || UNIFORM, "the matrix path needs one window width per tile");
+    static_assert(!MFMA || UNIFORM || RAG, "the matrix path needs one window width per tile");
+    // MIXED (ragged batches): per-lane lengths in general, but a tile whose 64 reads have ONE length --
+    // every tile of the usual fixed-length run handed over as offsets -- takes the matrix path and the
+    // uniform row walks; the other tiles walk the vector-ALU path.  Decided per tile, wave-uniformly.
+    constexpr bool MIXED = MFMA && !UNIFORM;
     static_assert(STAGE == 0 || (UNIFORM && !HAS_SEQ && NBUF == 1 && !SEG), "register staging: uniform batches, one buffer");
     static_assert(!SEG || (UNIFORM && MFMA && NBUF == 1), "segmented batches run the uniform matrix path, one buffer");
     // -n: NBUF == 2 keeps the quality and the sequence tile in two buffers (8 waves per CU);
@@ -409,7 +456,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             int mp = lane & 31;
             // segmented batches call this inside the tile loop: without the barrier the compiler hoists
             // the 48 per-byte position constants out of the loop and pins a register to each
-            if (SEG) asm volatile("" : "+v"(mp));
+            if (SEG || MIXED) asm volatile("" : "+v"(mp));
             const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
             const int win = 16 * hh + r;
             // band bytes of positions p .. p+3 (relative to 32*b): 1 where win <= position < win + wu
@@ -441,6 +488,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     auto probe = [&](uint64_t tt) -> sk_tile_view {
         sk_tile_view v;
         v.take = true;
+        v.uni = false;
         v.rowoff = 0;
         if (SEG) {
             const sk_tile_dev d = tiles[tt];
@@ -467,6 +515,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             v.rowoff = g.rowoff;
             v.r = (tt << 6) + lane;
             v.take = rag_tile_fits(g, buf_bytes);
+            v.uni = v.rows == 64u && __builtin_amdgcn_ballot_w64(g.len != g.lmax) == 0;
         } else {
             v.off = (tt << 6) * stride;
             v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
@@ -499,6 +548,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         for (uint32_t p = 0; p < cpr; ++p) {
             uint32_t ro;
             if (UNIFORM) ro = rr * stride;
+            else if (v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
             else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
             const uint32_t so = min(ro + GRAN * cc, lim);
             // a chunk may reach past its tile: harmless inside the batch, but the last chunks of the
@@ -574,6 +624,12 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 
         const bool active = (uint32_t)lane < cur.rows;
         const int Lv = UNIFORM ? 0 : cur.len; // mixed lengths: this lane's length (0 past the end of the batch)
+        bool tile_u = false; // MIXED: this tile's reads have one length (and a window the matrix path takes)
+        if (MIXED) {
+            const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
+            tile_u = cur.uni && l0 > 0 && l0 / 10 <= 65;
+            if (tile_u && l0 != Lu) set_length(l0);
+        }
 
         if (SEQ_SHARES || RAG) {
             tile = buf0;
@@ -613,7 +669,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         }
         if (!PROBE_EARLY && more) nxt = probe(tn);
         if (SEG && more) probe_index(nxt);
-        if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_wave_kernel's
+        if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_team_kernel's
+            // tell it that there is work: the word after the error word takes this scan's number (scans of a
+            // stream are ordered and numbered upwards, so the word never needs a reset)
+            if (lane == 0) atomicMax(errword + 1, (unsigned long long)a.scan_id);
             if (more && nxt.take) load_tile(qual, buf0, nxt);
             cur = nxt;
             continue;
@@ -637,9 +696,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         if (w == 0) w = L; // trim.cpp:30
         const int nwin = (UNIFORM ? scan_u : scanned) ? L - w + 1 : 0;
         const int m = w >> 2, sh = w & 3;
-        const int Lmax = UNIFORM ? L : wave_max(L);
-        const int wmax = UNIFORM ? w : wave_max(w);
-        const int nwinmax = UNIFORM ? nwin : wave_max(nwin);
+        // one value per wave: known (uniform batch), the lanes' common value (uniform tile of a ragged batch), or reduced
+        const int Lmax = UNIFORM ? L : tile_u ? __builtin_amdgcn_readfirstlane(L) : wave_max(L);
+        const int wmax = UNIFORM ? w : tile_u ? __builtin_amdgcn_readfirstlane(w) : wave_max(w);
+        const int nwinmax = UNIFORM ? nwin : tile_u ? __builtin_amdgcn_readfirstlane(nwin) : wave_max(nwin);
 
         // ---- range check of the whole read in 2 ops per dword: for a char c in [min,max],
         // |c-min| + |c-max| == max-min, and it is larger for every other byte value, so the
@@ -648,7 +708,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         uint32_t sad = 0;
         {
             int k = 0;
-            if (UNIFORM) {
+            if (UNIFORM || tile_u) {
                 const int full = Lmax >> 2; // whole dwords; rows are 8-byte aligned
                 const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
                 for (; k + 8 <= full; k += 8) { // 4 x ds_read_b64 in flight, then 16 SADs
@@ -707,7 +767,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             i1u = min(i1u, __builtin_elementwise_add_sat(ffbh_or_none(cand), (uint32_t)base)); // trim.cpp:61
         };
 
-        if (MFMA) {
+        if (MFMA && (UNIFORM || tile_u)) {
             // lane (n = lane&31, half): 16 bytes of read 32g+n at positions 32*kb + 16*half
             const uint8_t *frag0 = tile + (size_t)(lane & 31) * ts + 16 * half;
             const uint8_t *frag1 = frag0 + (size_t)32 * ts;
@@ -876,7 +936,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             };
             {
                 int k = 0;
-                if (UNIFORM) {
+                if (UNIFORM || tile_u) {
                     const int full = Lmax >> 2;
                     const uint64_t *srow64 = reinterpret_cast<const uint64_t *>(srow);
                     for (; k + 8 <= full; k += 8) {
@@ -980,26 +1040,28 @@ sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 namespace {
 
 template <int TEAM>
-__device__ __forceinline__ int team_min(int v)
+__device__ __forceinline__ int team_min(int v) // teams of 16 lanes are DPP rows
 {
-#pragma unroll
-    for (int o = TEAM / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    return TEAM == 16 ? row_min(v) : wave_min(v);
 }
 template <int TEAM>
 __device__ __forceinline__ uint32_t team_or(uint32_t v)
 {
-#pragma unroll
-    for (int o = TEAM / 2; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
+    return TEAM == 16 ? row_or(v) : wave_or(v);
 }
 template <int TEAM>
-__device__ __forceinline__ uint32_t team_scan_add(uint32_t v, int tl) // inclusive
+__device__ __forceinline__ uint32_t team_scan_add(uint32_t v, int tl) // inclusive prefix sum over the team
 {
-#pragma unroll
-    for (int o = 1; o < TEAM; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, o, TEAM);
-        if (tl >= o) v += t;
+    // within a row: row_shr:n reads the lane n to the left, lanes without one add nothing (bound_ctrl: 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    if (TEAM == 64) { // the rows before this lane's: their totals through scalar registers
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                       t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+        const int row = tl >> 4;
+        v += row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2;
     }
     return v;
 }
@@ -1171,21 +1233,37 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         const int sdw = s >> 2;
 
         // ---- 1. range check + chunk sum (trim.cpp:129 and the prefix of 31-33)
-        const int c4max = __builtin_amdgcn_readfirstlane(wave_max(scan ? c4 : 0));
         uint32_t sad = 0, csum = 0;
-        for (int k = 0; k < c4max; ++k) {
-            uint32_t x = min4;
-            int nval = 0;
-            if (scan && k < c4) {
-                x = row32[sdw + k];
-                nval = L - (s + 4 * k);
+        {
+            // whole dwords of the chunk that lie inside the read need no masking: four loads in flight
+            const int inner = scan ? min(c4, max(0, (L - s) >> 2)) : 0;
+            int k = 0;
+            for (; k + 4 <= inner; k += 4) {
+                uint32_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = row32[sdw + k + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sad = __builtin_amdgcn_sad_u8(x[u], min4, sad);
+                    sad = __builtin_amdgcn_sad_u8(x[u], max4, sad);
+                    csum = __builtin_amdgcn_sad_u8(x[u], 0u, csum);
+                }
             }
-            const uint32_t xq = first_bytes(x, nval, min4);
-            sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
-            sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
-            csum = __builtin_amdgcn_sad_u8(first_bytes(x, nval, 0u), 0u, csum);
+            for (; k < c4; ++k) { // the rest of the chunk: the read may end inside it
+                uint32_t x = min4;
+                int nval = 0;
+                if (scan) {
+                    x = row32[sdw + k];
+                    nval = L - (s + 4 * k);
+                }
+                const uint32_t xq = first_bytes(x, nval, min4);
+                sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+                sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+                csum = __builtin_amdgcn_sad_u8(first_bytes(x, nval, 0u), 0u, csum);
+            }
         }
-        const bool bad = scan && sad != (uint32_t)(4 * c4max * range);
+        // every dword visited contributes 4 * range when clean (fillers are legal chars)
+        const bool bad = scan && sad != (uint32_t)(4 * c4 * range);
         const uint32_t incl = team_scan_add<TEAM>(csum, tl);
 
         // ---- 2. S_s - T for this lane's first window: P(s + w) - P(s) - T
@@ -1342,14 +1420,20 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     };
 
     if (a.buf_bytes) {
-        // only the 64-read tiles sk_scan_tile_any_kernel left (the same test as there)
-        const uint64_t n_groups = (a.n_reads + 63) >> 6;
-        for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-            if (rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes)) continue;
-            for (uint64_t sub = 0; sub < (uint64_t)(64 / RPW); ++sub) {
-                const uint64_t slot = grp * (64 / RPW) + sub;
-                if (slot < n_slots) do_slot(slot);
+        // only the 64-read tiles sk_scan_tile_any_kernel left (the same test as there) -- if it left any:
+        // it has put this scan's number into the word after the error word for every tile it skipped
+        if (*reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
+        // slots (not tiles) are dealt to the waves, so that the reads of one left-over tile spread over the
+        // device; each wave asks the question for the tile its slot lies in (again only when the tile changes)
+        uint64_t asked = ~0ull;
+        bool fits = false;
+        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
+            const uint64_t grp = (slot * RPW) >> 6;
+            if (grp != asked) {
+                fits = rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes);
+                asked = grp;
             }
+            if (!fits) do_slot(slot);
         }
     } else {
         for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) do_slot(slot);
@@ -1564,11 +1648,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     if (a->truncn) {
         if (mfma) return launch(sk_scan_tile_any_kernel<true, true, true>);
         if (uniform) return launch(sk_scan_tile_any_kernel<true, true, false>);
-        return launch(sk_scan_tile_any_kernel<false, true, false>);
+        return launch(sk_scan_tile_any_kernel<false, true, true>);
     }
     if (mfma) return launch(sk_scan_tile_any_kernel<true, false, true>);
     if (uniform) return launch(sk_scan_tile_any_kernel<true, false, false>);
-    return launch(sk_scan_tile_any_kernel<false, false, false>);
+    return launch(sk_scan_tile_any_kernel<false, false, true>);
 }
 
 // diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py).
@@ -1620,9 +1704,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const
     if (per_cu > 16) per_cu = 16;
     if (per_cu < 1) return hipErrorInvalidValue;
     const uint64_t n_slots = (a->n_reads + rpw - 1) / rpw;
-    const uint64_t work = a->buf_bytes ? (a->n_reads + 63) >> 6 : n_slots; // tiles to look at, or slots
     uint64_t grid = (uint64_t)cu_count * per_cu;
-    if (grid > work) grid = work;
+    if (grid > n_slots) grid = n_slots;
     if (grid == 0) return hipSuccess;
     auto launch = [&](auto kern) {
         const kernel_facts facts = prepare_kernel(kern);
