@@ -25,7 +25,7 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
            "algorithmic_bytes_per_launch": line["algorithmic_bytes_per_launch"], "algorithmic_GBps_by_events": line["achieved"]}
     if stats:
         shutil.copyfile(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % v))
-        rows = [r for r in csv.DictReader(open(stats[0])) if want in r["Name"]]
+        rows = [r for r in csv.DictReader(open(stats[0])) if "sk_scan" in r["Name"]]
         ent["trace"] = [{"name": r["Name"][:100], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in rows]
         tot = sum(float(r["AverageNs"]) * int(r["Calls"]) for r in rows)
         # a variant may take two kernels per scan (ragged: tile + general): time per scan = total / scans
@@ -38,19 +38,21 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
         f = glob.glob(d + "*/*counter_collection.csv")
         if not f:
             continue
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        try:  # scans in THIS counter run (settle + steps), from the run's own JSON line
+            pl = json.loads(open(d.rstrip("/") + "_bench.json").read().strip().splitlines()[-1])
+            nscans = int(pl["scans_in_run"])
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for row in csv.DictReader(open(f[0])):
-            if "sk_scan" in row["Kernel_Name"]:
-                agg[row["Counter_Name"]][row["Dispatch_Id"]].append(float(row["Counter_Value"]))
+            if "sk_scan" in row["Kernel_Name"]:  # every kernel of the scan (a ragged scan launches two)
+                agg[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
         for k, per in agg.items():
-            vals = [sum(x) for x in per.values()]
-            counters[k] = {"dispatches": len(vals), "avg_per_dispatch": sum(vals) / len(vals)}
-    ent["counters_per_kernel_dispatch"] = counters
+            counters[k] = {"dispatches": len(per), "scans": nscans, "per_scan": sum(per.values()) / nscans}
+    ent["counters_per_scan"] = counters
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-        # per scan = per dispatch x kernels per scan (the counters were averaged over every sk_scan dispatch)
-        kps = (sum(t["calls"] for t in ent.get("trace", [])) / scans) if ent.get("trace") and scans else 1
-        fetch = counters["FETCH_SIZE"]["avg_per_dispatch"] * 1024 * 2 * kps
-        write = counters["WRITE_SIZE"]["avg_per_dispatch"] * 1024 * kps
+        fetch = counters["FETCH_SIZE"]["per_scan"] * 1024 * 2
+        write = counters["WRITE_SIZE"]["per_scan"] * 1024
         ent["hbm_bytes_per_scan"] = {"read": fetch, "write": write, "total": fetch + write,
                                      "over_algorithmic": (fetch + write) / line["algorithmic_bytes_per_launch"],
                                      "note": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 correction) + WRITE_SIZE (KB) x 1024; separate --pmc passes"}
