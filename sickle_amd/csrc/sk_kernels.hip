@@ -292,10 +292,11 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
 // row pitch of the LDS image the re-striding loader builds for reads of up to `len` bytes.  The loader
 // moves 16 bytes per lane, so a multiple of 16, with an ODD number of 16-byte units: the rows' 8-byte
 // reads (matrix path) then fall two lanes to a bank pair and their 4-byte reads (vector-ALU path) four
-// lanes to a bank -- the best 16-byte granules allow.  Measured alternative for the vector-ALU path:
-// 4 bytes per lane and a pitch of 4 * odd has no bank conflicts (SQ_LDS_BANK_CONFLICT 67 % -> 0 of
-// the LDS cycles on a 75-301 bp mix) but four times the DMA instructions, and is slower: 0.59 against
-// 0.46 ms on that mix, 0.67 against 0.61 ms on ragged 150 bp.
+// lanes to a bank -- the best 16-byte granules allow (SQ_LDS_BANK_CONFLICT is 56 % of the LDS cycles on
+// packed 150 bp).  Measured alternative: 4 bytes per lane and a pitch of 8 * odd (no conflicts, four
+// times the DMA instructions) is slower everywhere -- packed 150 bp 0.44 against 0.33 ms, ragged 150 bp
+// 0.56 against 0.42 ms, a 75-301 bp mix 0.59 against 0.46 ms: the loader's instruction count costs
+// more than the conflicts.
 template <bool UNIFORM>
 __device__ __forceinline__ uint32_t rag_pitch(uint32_t len)
 {
