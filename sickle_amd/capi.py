@@ -42,7 +42,7 @@ class Batch(C.Structure):
     _fields_ = [("qual", C.c_void_p), ("seq", C.c_void_p), ("offsets", C.c_void_p), ("stride", C.c_uint32),
                 ("read_len", C.c_uint32), ("lengths", C.c_void_p), ("n_reads", C.c_uint64),
                 ("tiles", C.c_void_p), ("n_tiles", C.c_uint32), ("out_index", C.c_void_p),
-                ("classes", C.c_void_p), ("n_classes", C.c_uint32)]
+                ("classes", C.c_void_p), ("n_classes", C.c_uint32), ("cuts_in_slot_order", C.c_uint32)]
 
 
 class SegClass(C.Structure):
@@ -167,9 +167,9 @@ class Context:
         raise SickleError("libsickle_amd call failed (%d): %s" % (rc, lib().sk_last_error(self._h).decode()))
 
     # ---- host buffers (numpy) -------------------------------------------------------------
-    def trim_segmented(self, params, qual, tiles, out_index, max_stride, seq=None):
+    def trim_segmented(self, params, qual, tiles, out_index, max_stride, seq=None, slot_order=False):
         """sk_trim_batch on a segmented batch (tiles: numpy array of TILE_DTYPE) -> cuts[n,2] int32
-        in the caller's read order (out_index)."""
+        in the caller's read order (out_index), or in slot order with slot_order=True."""
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         seq = None if seq is None else np.ascontiguousarray(seq, dtype=np.uint8)
         tiles = np.ascontiguousarray(tiles, dtype=TILE_DTYPE)
@@ -177,7 +177,7 @@ class Context:
         n = len(out_index)
         out = np.full((n, 2), -7, dtype=np.int32)
         b = Batch(_np_ptr(qual), _np_ptr(seq), None, max_stride, 0, None, n, tiles.ctypes.data, len(tiles),
-                  out_index.ctypes.data)
+                  out_index.ctypes.data, None, 0, 1 if slot_order else 0)
         err = Err()
         rc = lib().sk_trim_batch(self._h, C.byref(params), C.byref(b), out.ctypes.data, C.byref(err))
         self._check(rc, err)

@@ -451,6 +451,8 @@ void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
         b.tiles = s.tiles.data();
         b.n_tiles = (uint32_t)s.tiles.size();
         b.out_index = out_index;
+        b.cuts_in_slot_order = 1;
+        s.slot_order = true;
     } else if (tiled) {
         const size_t stride = stride_for(len0);
         grow(ctx, s, n * stride, n, need_seq);
@@ -479,6 +481,7 @@ void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
         });
         b.offsets = s.offsets;
     }
+    if (!segmented) s.slot_order = false;
     b.qual = s.qual;
     b.seq = need_seq ? s.seq : nullptr;
     b.n_reads = n;
@@ -513,7 +516,19 @@ const cutsites *Abstract_Trimmer::wait_scan(int slot, const RawVec<FQEntry> &rea
         fprintf(stderr, "****Error: device scan failed (%d): %s\n\n", rc, sk_last_error(ctx));
         fatal_exit(EXIT_FAILURE);
     }
-    return reinterpret_cast<const cutsites *>(slots[(size_t)slot].cuts);
+    Slot &s = slots[(size_t)slot];
+    const cutsites *cuts = reinterpret_cast<const cutsites *>(s.cuts);
+    if (!s.slot_order) return cuts;
+    // slot order -> read order (the index buffer of a segmented batch lives in s.offsets)
+    const size_t n = reads.size();
+    const uint32_t *out_index = reinterpret_cast<const uint32_t *>(s.offsets);
+    s.ordered.resize(n);
+    cutsites *ordered = s.ordered.data();
+    WorkerPool &pool = WorkerPool::instance();
+    pool.parallel_for(n, (size_t)pool.size(), [&](size_t lo, size_t hi, size_t) {
+        for (size_t k = lo; k < hi; ++k) ordered[out_index[k]] = cuts[k];
+    });
+    return ordered;
 }
 
 std::thread Abstract_Trimmer::prefetch_batches(GZReader *reader, Channel<Batch *> &out)

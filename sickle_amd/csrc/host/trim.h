@@ -202,6 +202,10 @@ private:
         sk_cut *cuts = nullptr;
         size_t cap_reads = 0;
         std::vector<sk_tile> tiles; // segmented batches: one descriptor per tile
+        // segmented batches come back in slot order (one coalesced stream of cuts on the device);
+        // wait_scan puts them into read order here, through the out_index it packed
+        bool slot_order = false;
+        std::vector<cutsites> ordered;
     };
     std::vector<int> device_ids; // set by open_device() before it returns
     std::vector<sk_ctx *> ctxs;  // one per entry of device_ids, created by the opener thread

@@ -151,6 +151,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     static const int order = [] { const char *e = getenv("SK_TILE_ORDER"); return e ? atoi(e) : 0; }();
     a->tile_order = order;
     a->buf_bytes = 0;
+    a->slot_order = (b->tiles && b->cuts_in_slot_order) ? 1 : 0;
     a->scan_id = 0;
     a->team_rbuf = 0;
     a->team_maxlen = 0;

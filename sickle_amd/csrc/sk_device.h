@@ -46,6 +46,7 @@ struct sk_scan_args {
     uint32_t n_tiles;   // segmented batches: number of tile descriptors
     int32_t tile_order; // diagnostic (SK_TILE_ORDER): 0 = tile t on workgroup t mod G, 1 = contiguous tile ranges per XCD
     uint32_t buf_bytes; // LDS bytes per wave (segmented / rows at any address); general kernel: != 0 = only the tiles that do not fit them
+    int32_t slot_order;   // segmented batches: cuts written in slot order, out_index only names erroring reads
     uint64_t scan_id;     // number of this scan on its error word (ragged batches: tile kernel -> general kernel hand-over)
     uint32_t team_rbuf;   // general kernel: LDS bytes of one read's buffer
     uint32_t team_maxlen; // general kernel: the longest read that goes through LDS

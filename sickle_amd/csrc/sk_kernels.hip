@@ -532,7 +532,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // load (not counted by vmcnt: it can be issued before the wait for the tile); the index is a vector
     // load that needs the descriptor, issued after that wait, when the descriptor has long arrived
     auto probe_index = [&](sk_tile_view &v) {
-        v.r = (uint64_t)out_index[(uint32_t)v.r + min((uint32_t)lane, v.rows - 1u)];
+        const uint32_t slot = (uint32_t)v.r + min((uint32_t)lane, v.rows - 1u);
+        v.r = a.slot_order ? (uint64_t)slot : (uint64_t)out_index[slot]; // slot order: one coalesced stream of cuts
     };
 
     // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, chunks per row)
@@ -905,7 +906,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     uint32_t f = keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
                     if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
                 }
-                if (p < touched) report_error(errword, r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
+                // (segmented batches in slot order: the caller's read number comes from out_index here only)
+                if (p < touched) report_error(errword, (SEG && a.slot_order) ? (uint64_t)out_index[r] : r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
             }
         }
 

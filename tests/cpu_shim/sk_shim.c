@@ -64,8 +64,9 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *p, const sk_batch *b, sk_c
                 const uint64_t off = d->byte_off + (uint64_t)i * d->stride;
                 const uint32_t dst = b->out_index[d->slot0 + i];
                 sko_err e1 = {0, 0, 0};
+                /* cuts_in_slot_order: the cut goes to the read's slot; the error still names the caller's read */
                 if (sko_sliding_window(&op, b->seq ? b->seq + off : NULL, b->qual + off, d->read_len,
-                                       (sko_cut *)&out[dst], &e1)) {
+                                       (sko_cut *)&out[b->cuts_in_slot_order ? d->slot0 + i : dst], &e1)) {
                     ctx->rc[slot] = 1;
                     if (dst < best) {
                         best = dst;

@@ -151,11 +151,11 @@ def test_mixed_lengths_illumina_trunc_n_12m(sk_ctx):
     oi = torch.from_numpy(order.astype(np.uint32).view(np.int32)).to(dev)
     cls, ncls = capi.seg_classes(tiles)
 
-    def seg_scan(q_t):
+    def seg_scan(q_t, slot_order=0):
         out = torch.empty((n, 2), dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
         b = capi.Batch(q_t.data_ptr(), segs.data_ptr(), None, int(tiles["stride"].max()), 0, None, n, tiles_t.data_ptr(), len(tiles),
-                       oi.data_ptr(), C.cast(cls, C.c_void_p) if ncls else None, ncls)
+                       oi.data_ptr(), C.cast(cls, C.c_void_p) if ncls else None, ncls, slot_order)
         rc = capi.lib().sk_scan_device_async(sk_ctx._h, C.byref(p), C.byref(b), out.data_ptr(), None)
         assert rc == 0
         return out
@@ -163,6 +163,11 @@ def test_mixed_lengths_illumina_trunc_n_12m(sk_ctx):
     seg = seg_scan(segq)
     sk_ctx.scan_device_finish()
     assert bool((seg == ragged).all()), "segmented and ragged kernels disagree"
+    # cuts left in slot order (what the CLI asks for): slot k holds the cut of read order[k]
+    seg_slots = seg_scan(segq, 1)
+    sk_ctx.scan_device_finish()
+    assert bool((seg_slots == ragged[torch.from_numpy(order.astype(np.int64)).to(dev)]).all())
+    del seg_slots
     kept = int((seg[:, 1] >= 0).sum())
     assert 0.5 * n < kept < n
 
@@ -178,7 +183,8 @@ def test_mixed_lengths_illumina_trunc_n_12m(sk_ctx):
     victims = [9_876_543, 2_345_678]
     for v in victims:
         segq[int(dst_h[v]) + 5] = 20
-    seg_scan(segq)
-    with pytest.raises(capi.RangeError) as ei:
-        sk_ctx.scan_device_finish()
-    assert (ei.value.read, ei.value.pos, ei.value.ch) == (2_345_678, 5, 20)
+    for slot_order in (0, 1):
+        seg_scan(segq, slot_order)
+        with pytest.raises(capi.RangeError) as ei:
+            sk_ctx.scan_device_finish()
+        assert (ei.value.read, ei.value.pos, ei.value.ch) == (2_345_678, 5, 20)

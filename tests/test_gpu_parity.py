@@ -341,6 +341,9 @@ def test_segmented_batches(sk_ctx):
         got = sk_ctx.trim_segmented(p, qs, tiles, out_index, max_stride, seq=ss)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert bad.size == 0, (q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], np.diff(offsets)[bad[:5]])
+        # the same with the cuts left in slot order (what the CLI asks for): slot k holds read out_index[k]
+        got = sk_ctx.trim_segmented(p, qs, tiles, out_index, max_stride, seq=ss, slot_order=True)
+        assert (got == want[out_index]).all(), (q, l, x, tn, "slot order")
     # range error: reported with the ORIGINAL read index, lowest original index first
     q2 = qual.copy()
     victims = [25_000, 7_777]
@@ -348,9 +351,10 @@ def test_segmented_batches(sk_ctx):
         q2[int(offsets[v]) + 3] = 20
     ss2, qs2, tiles2, oi2, ms2 = segment_by_length(seq, q2, offsets)
     p, _ = both_params("illumina", 20, 0, 0, 0)
-    with pytest.raises(capi.RangeError) as ei:
-        sk_ctx.trim_segmented(p, qs2, tiles2, oi2, ms2, seq=ss2)
-    assert (ei.value.read, ei.value.pos, ei.value.ch) == (7_777, 3, 20)
+    for slot_order in (False, True):  # the error names the caller's read either way
+        with pytest.raises(capi.RangeError) as ei:
+            sk_ctx.trim_segmented(p, qs2, tiles2, oi2, ms2, seq=ss2, slot_order=slot_order)
+        assert (ei.value.read, ei.value.pos, ei.value.ch) == (7_777, 3, 20)
 
 
 def test_register_staged_tiles(sk_ctx):

@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-NAMES = ("n150", "u250", "u100", "seg", "seg_n", "packed150", "ragged150", "ragged_mix", "long")
+NAMES = ("n150", "u250", "u100", "seg", "seg_n", "seg_scatter", "packed150", "ragged150", "ragged_mix", "long")
 
 
 def _quals(torch, shape, dev, seed):
@@ -79,8 +79,9 @@ def build(name, torch, capi, ctx, dev, stream, bench):
         d = uniform(150, 10_000_000, False, stride=150)
         d["workload"] = "150 bp reads packed back to back (stride 150): tiles re-strided into LDS, " + d["workload"]
         return dict(d, keep=keep)
-    if name in ("seg", "seg_n"):
+    if name in ("seg", "seg_n", "seg_scatter"):
         with_seq = name == "seg_n"
+        slot_order = name != "seg_scatter"  # the CLI takes its cuts in slot order and un-permutes on the host
         m = 4_000_000
         rng = np.random.default_rng(11)
         lens = rng.integers(75, 302, size=m)
@@ -100,14 +101,15 @@ def build(name, torch, capi, ctx, dev, stream, bench):
 
         def go():
             b = capi.Batch(q.data_ptr(), seq.data_ptr() if with_seq else None, None, max_stride, 0, None, m, tiles_t.data_ptr(),
-                           len(tiles), oi.data_ptr(), C.cast(cls, C.c_void_p) if ncls else None, ncls)
+                           len(tiles), oi.data_ptr(), C.cast(cls, C.c_void_p) if ncls else None, ncls, 1 if slot_order else 0)
             rc = lib.sk_scan_device_async(ctx._h, C.byref(par), C.byref(b), out.data_ptr(), sp)
             if rc != 0:
                 raise capi.SickleError("sk_scan_device_async(segmented) -> %d" % rc)
         tot = int(lens.sum())
         return dict(launch=go, n_reads=m, algo_bytes=(2 if with_seq else 1) * tot + 8 * m, kernel="sk_scan_tile_kernel",
-                    workload="segmented: %d reads of U{75..301} bp grouped by length into %d tiles, cuts scattered back to "
-                             "input order%s" % (m, len(tiles), ", -n" if with_seq else ""), keep=keep)
+                    workload="segmented: %d reads of U{75..301} bp grouped by length into %d tiles, cuts %s%s"
+                             % (m, len(tiles), "in slot order (the caller un-permutes, as the CLI does)" if slot_order
+                                else "scattered back to input order on the device", ", -n" if with_seq else ""), keep=keep)
     if name in ("ragged150", "ragged_mix", "long"):
         g = torch.Generator(device=dev)
         g.manual_seed(17)
