@@ -209,6 +209,23 @@ int sk_kernel_for(const sk_batch *batch);
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */
 const char *sk_kernel_name(int which);
 
+/*
+ * Pair classification on the device: reference src/trim_paired.cpp:543-567.  `cuts` (DEVICE pointer, the
+ * output of a scan in read order) holds the mates of pair k at 2k and 2k+1; a mate is kept iff its three >= 0
+ * (src/trim_paired.cpp:500,502).  Counts the four classes into the context (per stream, like the error word)
+ * and, if classes != NULL (device pointer, n_pairs bytes), writes each pair's class: SK_PAIR_BOTH (both kept:
+ * two paired records), SK_PAIR_FIRST / SK_PAIR_SECOND (one single record), SK_PAIR_NONE.  The reference's
+ * six counters follow: kept_p = 2*both, kept_s1 = discard_s2 = only_first, kept_s2 = discard_s1 =
+ * only_second, discard_p = 2*none.  Enqueued on hip_stream behind the scan that produced `cuts`.
+ */
+enum { SK_PAIR_BOTH = 0, SK_PAIR_FIRST = 1, SK_PAIR_SECOND = 2, SK_PAIR_NONE = 3 };
+typedef struct {
+    uint64_t both, only_first, only_second, none; /* pairs */
+} sk_pair_counts;
+int sk_count_pairs_device_async(sk_ctx *ctx, const sk_cut *cuts, uint64_t n_pairs, uint8_t *classes, void *hip_stream);
+/* Waits for the stream, returns and clears the counts accumulated on it since the last finish. */
+int sk_count_pairs_device_finish(sk_ctx *ctx, void *hip_stream, sk_pair_counts *counts);
+
 /* Measurement aid (bench.py's second roofline denominator): streams `bytes` of device memory at
  * dev_buf through a read-only kernel (16-byte nt loads, nothing written) `launches` times on
  * hip_stream and returns the average rate in GB/s, timed with HIP events on that stream. */

@@ -16,7 +16,8 @@ QUALTYPES = {"phred": 0, "sanger": 1, "solexa": 2, "illumina": 3}
 EXPORTS = ("sk_quality_constants", "sk_typename", "sk_abi_version", "sk_device_count", "sk_create",
            "sk_destroy", "sk_last_error", "sk_device", "sk_host_alloc", "sk_host_free",
            "sk_scan_device_async", "sk_scan_device_finish", "sk_trim_batch", "sk_submit", "sk_wait",
-           "sk_kernel_for", "sk_kernel_name", "sk_seg_classes", "sk_probe_read_bandwidth", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
+           "sk_kernel_for", "sk_kernel_name", "sk_seg_classes", "sk_probe_read_bandwidth",
+           "sk_count_pairs_device_async", "sk_count_pairs_device_finish", "sk_bgzf_deflate", "sk_bgzf_host_alloc", "sk_bgzf_host_free",
            "sk_bgzf_last_error")
 
 
@@ -54,6 +55,10 @@ def seg_classes(tiles, max_classes=16):
     arr = (SegClass * max_classes)()
     n = lib().sk_seg_classes(tiles.ctypes.data, len(tiles), arr, max_classes)
     return arr, n
+
+
+class PairCounts(C.Structure):
+    _fields_ = [("both", C.c_uint64), ("only_first", C.c_uint64), ("only_second", C.c_uint64), ("none", C.c_uint64)]
 
 
 class SickleError(RuntimeError):
@@ -120,6 +125,10 @@ def lib():
         L.sk_kernel_name.argtypes = [C.c_int]
         L.sk_probe_read_bandwidth.restype = C.c_int
         L.sk_probe_read_bandwidth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        L.sk_count_pairs_device_async.restype = C.c_int
+        L.sk_count_pairs_device_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.sk_count_pairs_device_finish.restype = C.c_int
+        L.sk_count_pairs_device_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PairCounts)]
         L.sk_seg_classes.restype = C.c_uint32
         L.sk_seg_classes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.sk_bgzf_deflate.restype = C.c_int
@@ -220,6 +229,13 @@ class Context:
         g = C.c_double()
         self._check(lib().sk_probe_read_bandwidth(self._h, dev_ptr, nbytes, launches, stream, C.byref(g)))
         return g.value
+
+    def count_pairs_device(self, cuts_ptr, n_pairs, classes_ptr=None, stream=None):
+        """Pair classes of the cuts at cuts_ptr (mates at 2k, 2k+1) -> (both, only_first, only_second, none)."""
+        self._check(lib().sk_count_pairs_device_async(self._h, cuts_ptr, n_pairs, classes_ptr, stream))
+        c = PairCounts()
+        self._check(lib().sk_count_pairs_device_finish(self._h, stream, C.byref(c)))
+        return c.both, c.only_first, c.only_second, c.none
 
     def scan_device_finish(self, stream=None):
         err = Err()

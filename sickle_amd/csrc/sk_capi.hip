@@ -61,7 +61,7 @@ struct sk_ctx {
     // ... and one per other stream the caller scans on: errors of scans enqueued on different streams do
     // not meet in one word (each sk_scan_device_finish reports what ITS stream's scans found)
     struct ErrWord {
-        unsigned long long *d = nullptr, *h = nullptr;
+        unsigned long long *d = nullptr, *h = nullptr; // d: error word, hand-over word, four pair counters (6 x 8 bytes)
     };
     std::map<hipStream_t, ErrWord> stream_err;
     std::mutex stream_err_lock;
@@ -233,10 +233,10 @@ int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigne
     sk_ctx::ErrWord &w = ctx->stream_err[stream];
     if (!w.d) {
         SK_HIP(ctx, hipSetDevice(ctx->device));
-        SK_HIP(ctx, hipMalloc(&w.d, 2 * sizeof(unsigned long long)));
+        SK_HIP(ctx, hipMalloc(&w.d, 6 * sizeof(unsigned long long)));
         SK_HIP(ctx, hipMemset(w.d, 0xff, sizeof(unsigned long long))); // synchronous: done before any scan is enqueued
-        SK_HIP(ctx, hipMemset(w.d + 1, 0, sizeof(unsigned long long)));
-        SK_HIP(ctx, hipHostMalloc(&w.h, sizeof(unsigned long long), hipHostMallocDefault));
+        SK_HIP(ctx, hipMemset(w.d + 1, 0, 5 * sizeof(unsigned long long)));
+        SK_HIP(ctx, hipHostMalloc(&w.h, 6 * sizeof(unsigned long long), hipHostMallocDefault));
         *w.h = kNoError;
     }
     *d = w.d;
@@ -361,10 +361,10 @@ int sk_create(int device, int slots, sk_ctx **out)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    SK_TRY(hipMalloc(&ctx->d_err, 2 * sizeof(unsigned long long)));
+    SK_TRY(hipMalloc(&ctx->d_err, 6 * sizeof(unsigned long long)));
     SK_TRY(hipMemset(ctx->d_err, 0xff, sizeof(unsigned long long)));
-    SK_TRY(hipMemset(ctx->d_err + 1, 0, sizeof(unsigned long long))); // the hand-over word (see enqueue_scan)
-    SK_TRY(hipHostMalloc(&ctx->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    SK_TRY(hipMemset(ctx->d_err + 1, 0, 5 * sizeof(unsigned long long))); // the hand-over word (see enqueue_scan), four pair counters
+    SK_TRY(hipHostMalloc(&ctx->h_err, 6 * sizeof(unsigned long long), hipHostMallocDefault));
     *ctx->h_err = kNoError;
     ctx->slots.resize((size_t)slots);
     for (Slot &s : ctx->slots) {
@@ -498,6 +498,34 @@ const char *sk_kernel_name(int which)
     case 5: return "sk_scan_tile_any_kernel";
     default: return "";
     }
+}
+
+int sk_count_pairs_device_async(sk_ctx *ctx, const sk_cut *cuts, uint64_t n_pairs, uint8_t *classes, void *hip_stream)
+{
+    if (!ctx || (!cuts && n_pairs) || (reinterpret_cast<uintptr_t>(cuts) & 15)) return SK_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    unsigned long long *d, *h;
+    int rc = err_word_of(ctx, stream, &d, &h);
+    if (rc != SK_OK) return rc;
+    SK_HIP(ctx, sk_launch_pair_count(reinterpret_cast<const sk_cut_dev *>(cuts), n_pairs, classes, d + 2, ctx->cu_count, stream));
+    return SK_OK;
+}
+
+int sk_count_pairs_device_finish(sk_ctx *ctx, void *hip_stream, sk_pair_counts *counts)
+{
+    if (!ctx || !counts) return SK_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    unsigned long long *d, *h;
+    int rc = err_word_of(ctx, stream, &d, &h);
+    if (rc != SK_OK) return rc;
+    SK_HIP(ctx, hipMemcpyAsync(h + 2, d + 2, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SK_HIP(ctx, hipMemsetAsync(d + 2, 0, 4 * sizeof(unsigned long long), stream));
+    SK_HIP(ctx, hipStreamSynchronize(stream));
+    counts->both = h[2];
+    counts->only_first = h[3];
+    counts->only_second = h[4];
+    counts->none = h[5];
+    return SK_OK;
 }
 
 int sk_probe_read_bandwidth(sk_ctx *ctx, const void *dev_buf, size_t bytes, int launches, void *hip_stream, double *gb_per_s)

@@ -67,6 +67,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_pair_count(const sk_cut_dev *cuts, uint64_t n_pairs, uint8_t *classes,
+                                           unsigned long long *counters, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_read_probe(const void *buf, size_t bytes, uint32_t *sink, int cu_count,
                                            hipStream_t stream);
 #endif

@@ -1748,3 +1748,45 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_read_probe
                        reinterpret_cast<const sk_v4u *>(buf), bytes / 16, sink);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// pair classification: reference src/trim_paired.cpp:543-567 over the cuts of a scan (mates at 2k, 2k+1).
+// One 16-byte load per pair and lane; the four class counts of a wave come from ballots, one lane adds them.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sk_pair_count_kernel(const sk_v4i *__restrict__ cuts, uint64_t n_pairs, uint8_t *__restrict__ classes,
+                                                            unsigned long long *counters)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    unsigned long long c_both = 0, c_first = 0, c_second = 0, c_none = 0; // per wave, kept by every lane
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_pairs; k0 += stride) {
+        const uint64_t k = k0 + threadIdx.x;
+        int cls = -1;
+        if (k < n_pairs) {
+            const sk_v4i c = __builtin_nontemporal_load(cuts + k); // {five1, three1, five2, three2}
+            const bool r1 = c[1] >= 0, r2 = c[3] >= 0;             // src/trim_paired.cpp:500,502
+            cls = r1 ? (r2 ? 0 : 1) : (r2 ? 2 : 3);
+            if (classes) classes[k] = (uint8_t)cls;
+        }
+        c_both += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 0));
+        c_first += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 1));
+        c_second += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 2));
+        c_none += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 3));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (c_both) atomicAdd(counters + 0, c_both);
+        if (c_first) atomicAdd(counters + 1, c_first);
+        if (c_second) atomicAdd(counters + 2, c_second);
+        if (c_none) atomicAdd(counters + 3, c_none);
+    }
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_pair_count(const sk_cut_dev *cuts, uint64_t n_pairs, uint8_t *classes,
+                                           unsigned long long *counters, int cu_count, hipStream_t stream)
+{
+    if (n_pairs == 0) return hipSuccess;
+    uint64_t grid = (n_pairs + 255) / 256;
+    if (grid > (uint64_t)cu_count * 16) grid = (uint64_t)cu_count * 16;
+    hipLaunchKernelGGL(sk_pair_count_kernel, dim3((unsigned)grid), dim3(256), 0, stream, reinterpret_cast<const sk_v4i *>(cuts), n_pairs,
+                       classes, counters);
+    return hipGetLastError();
+}

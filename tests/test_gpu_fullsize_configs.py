@@ -57,10 +57,17 @@ def test_100m_reads_resident(sk_ctx):
     got = a[s0:s0 + sm].cpu().numpy()
     assert err is None and (got == want).all()
     assert pair_classes(got) == pair_classes(want)
-    # whole batch as 50 M pairs: the four classes partition it
+    # whole batch as 50 M pairs: the four classes partition it; the device's own classification
+    # (sk_count_pairs_device_*: src/trim_paired.cpp:543-567) gives the same counts and per-pair classes
     k1, k2 = a[0::2, 1] >= 0, a[1::2, 1] >= 0
     classes = [int((k1 & k2).sum()), int((k1 & ~k2).sum()), int((~k1 & k2).sum()), int((~k1 & ~k2).sum())]
     assert sum(classes) == N // 2 and classes[0] > 0.99 * (N // 2)
+    cls_dev = torch.empty((N // 2,), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    assert list(sk_ctx.count_pairs_device(a.data_ptr(), N // 2, cls_dev.data_ptr())) == classes
+    want_cls = torch.where(k1, torch.where(k2, 0, 1), torch.where(k2, 2, 3)).to(torch.uint8)
+    assert bool((cls_dev == want_cls).all())
+    assert list(sk_ctx.count_pairs_device(a[2 * (s0 // 2):].data_ptr(), sm // 2)) == list(pair_classes(want))  # the oracle's sample
 
 
 def test_shard_of_12_5m_reads_through_submit_wait(sk_ctx):

@@ -424,3 +424,25 @@ def test_streams_keep_their_own_range_errors(sk_ctx):
     sk_ctx.scan_device_async(p, bufs[2][0].data_ptr(), bufs[2][1].data_ptr(), n, stride=152, read_len=150, stream=s2.cuda_stream)
     sk_ctx.scan_device_finish(s2.cuda_stream)  # clean: the earlier error was consumed
     assert bool((bufs[2][1][:, 1] == 150).all())
+
+
+def test_pair_classification_on_device(sk_ctx):
+    """sk_count_pairs_device_*: the four pair classes of reference src/trim_paired.cpp:543-567 from cuts on the
+    device, against numpy on the same cuts (all class mixes, odd sizes, an empty batch, counts cleared per finish)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    for n_pairs in (0, 1, 63, 64, 65, 1000, 300_001):
+        cuts = np.zeros((2 * n_pairs, 2), dtype=np.int32)
+        cuts[:, 1] = np.where(rng.random(2 * n_pairs) < 0.6, rng.integers(0, 150, 2 * n_pairs), rng.choice([-1, -2], 2 * n_pairs))
+        cuts[:, 0] = np.where(cuts[:, 1] >= 0, 0, -1)
+        k1, k2 = cuts[0::2, 1] >= 0, cuts[1::2, 1] >= 0
+        want = (int((k1 & k2).sum()), int((k1 & ~k2).sum()), int((~k1 & k2).sum()), int((~k1 & ~k2).sum()))
+        t = torch.from_numpy(cuts).to(dev)
+        cls = torch.full((max(1, n_pairs),), 9, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        assert sk_ctx.count_pairs_device(t.data_ptr(), n_pairs, cls.data_ptr()) == want
+        assert sk_ctx.count_pairs_device(t.data_ptr(), n_pairs) == want  # counters were cleared by the finish
+        if n_pairs:
+            want_cls = np.where(k1, np.where(k2, 0, 1), np.where(k2, 2, 3)).astype(np.uint8)
+            assert (cls.cpu().numpy()[:n_pairs] == want_cls).all()
