@@ -446,3 +446,33 @@ def test_pair_classification_on_device(sk_ctx):
         if n_pairs:
             want_cls = np.where(k1, np.where(k2, 0, 1), np.where(k2, 2, 3)).astype(np.uint8)
             assert (cls.cpu().numpy()[:n_pairs] == want_cls).all()
+
+
+def test_misaligned_base_pointers_and_odd_strides(sk_ctx):
+    """Device buffers that do not start on a 16-byte boundary, strides that are not multiples of 8, with and without
+    -n: every combination takes the re-striding loader (or the aligned kernels when it can) and must give the
+    oracle's cuts; the last reads of the buffer sit right at its end (nothing may be read past it)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, L = 5_003, 150
+    seq, qual = synth.make_reads(31, n, L, "sanger", lower_n_frac=0.01)
+    for stride in (150, 151, 152, 157):
+        qs, ss = synth.pack_fixed(qual, stride), synth.pack_fixed(seq, stride)
+        for shift_q, shift_s in ((0, 0), (3, 0), (5, 9), (16, 1)):
+            # exact-size device buffers: the batch ends where the allocation's used part ends
+            tq = torch.zeros(shift_q + n * stride, dtype=torch.uint8, device=dev)
+            ts = torch.zeros(shift_s + n * stride, dtype=torch.uint8, device=dev)
+            tq[shift_q:] = torch.from_numpy(qs.reshape(-1)).to(dev)
+            ts[shift_s:] = torch.from_numpy(ss.reshape(-1)).to(dev)
+            for tn in (False, True):
+                p, po = both_params("sanger", 20, 20, 0, tn)
+                want, err = ob.oracle_trim_batch(po, qs, ss, stride=stride, read_len=L, n_reads=n, threads=4)
+                assert err is None
+                out = torch.full((n, 2), -7, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize(dev)
+                sk_ctx.scan_device_async(p, tq.data_ptr() + shift_q, out.data_ptr(), n, stride=stride, read_len=L,
+                                         seq_ptr=ts.data_ptr() + shift_s)
+                sk_ctx.scan_device_finish()
+                got = out.cpu().numpy()
+                bad = np.nonzero((got != want).any(axis=1))[0]
+                assert bad.size == 0, (stride, shift_q, shift_s, tn, bad[:5], got[bad[:5]], want[bad[:5]])
