@@ -591,7 +591,16 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         return p == STAGE - 1 ? min(off, full_bytes - 16u) : off;
     };
 
-    uint64_t t = wave_global;
+    // Which tiles a wave takes: tile t, then t + (number of waves), ... -- except in segmented batches, where a
+    // wave takes SEG_CHUNK consecutive tiles at a time.  There the tiles are sorted by length, and with single
+    // steps every wave met a new length at every tile (its tiles lie `waves` apart) and rebuilt the band matrix
+    // each time (set_length: ~150 instructions against ~600 for the tile's scan); a chunk shares one length.
+    constexpr uint64_t SEG_CHUNK = 4;
+    auto next_tile = [&](uint64_t tt) -> uint64_t {
+        if (SEG) return ((tt + 1) % SEG_CHUNK != 0) ? tt + 1 : tt + 1 + (wave_count - 1) * SEG_CHUNK;
+        return tt + wave_count;
+    };
+    uint64_t t = SEG ? wave_global * SEG_CHUNK : wave_global;
     if (t >= n_tiles) return;
 
     // prologue: Q(t) [and S(t)] in flight
@@ -612,8 +621,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // vmcnt(0), and a load issued just before it would put its whole latency on every tile
     constexpr bool PROBE_EARLY = NBUF == 2 || STAGE != 0 || ABLATE != 0 || SEG != 0;
 
-    for (; t < n_tiles; t += wave_count) {
-        const uint64_t tn = t + wave_count;
+    for (; t < n_tiles; t = next_tile(t)) {
+        const uint64_t tn = next_tile(t);
         const bool more = tn < n_tiles;
         if (PROBE_EARLY && more) nxt = probe(tn);
         const uint32_t ts = cur.ts;  // this tile's row pitch in LDS
@@ -1602,7 +1611,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
         int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
         if (per_cu > 16) per_cu = 16;
         uint64_t grid = (uint64_t)cu_count * per_cu;
-        if (grid > k.n_tiles) grid = k.n_tiles;
+        const uint64_t chunks = ((uint64_t)k.n_tiles + 3) / 4; // a wave takes 4 consecutive tiles at a time (SEG_CHUNK)
+        if (grid > chunks) grid = chunks;
         sk_scan_args as = *a;
         as.buf_bytes = lds_bytes;
         as.n_tiles = k.n_tiles;

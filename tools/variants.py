@@ -73,21 +73,26 @@ def build(name, torch, capi, ctx, dev, stream, bench):
         return dict(uniform(150, 10_000_000, True), keep=keep)
     if name == "u250":
         return dict(uniform(250, 4_000_000, False), keep=keep)
+    if name == "u150":  # diagnostic (with SK_TILE_STAGE=0: the LDS-DMA kernel the segmented one is built on)
+        return dict(uniform(150, 10_000_000, False), keep=keep)
     if name == "u100":
         return dict(uniform(100, 10_000_000, False), keep=keep)
     if name == "packed150":
         d = uniform(150, 10_000_000, False, stride=150)
         d["workload"] = "150 bp reads packed back to back (stride 150): tiles re-strided into LDS, " + d["workload"]
         return dict(d, keep=keep)
-    if name in ("seg", "seg_n", "seg_scatter"):
+    if name in ("seg", "seg_n", "seg_scatter", "seg150"):
         with_seq = name == "seg_n"
         slot_order = name != "seg_scatter"  # the CLI takes its cuts in slot order and un-permutes on the host
         m = 4_000_000
         rng = np.random.default_rng(11)
         lens = rng.integers(75, 302, size=m)
+        if name == "seg150":  # diagnostic: one length, the segmented kernel against the uniform ones
+            m = 10_000_000
+            lens = np.full(m, 150)
         order = np.argsort(lens, kind="stable").astype(np.uint32)  # slot -> the read's place in the caller's order
         counts = np.bincount(lens, minlength=302)
-        tiles, nbytes, nreads = _seg_layout([(L, int(counts[L])) for L in range(75, 302)])
+        tiles, nbytes, nreads = _seg_layout([(L, int(counts[L])) for L in range(75, 302)])  # noqa
         assert nreads == m
         q = _quals(torch, (nbytes,), dev, 21)
         seq = torch.full((nbytes + 4096,), 65, dtype=torch.uint8, device=dev) if with_seq else None
