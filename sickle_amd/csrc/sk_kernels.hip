@@ -1175,6 +1175,7 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
 {
     static_assert(TEAM == 16 || TEAM == 64, "teams of 16 or 64 lanes");
     constexpr int RPW = 64 / TEAM; // reads per wave
+    constexpr bool SKIP = TEAM == 64; // whole-wave teams: prefix table + skip-ahead window search (see do_slot)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x; // single-wave workgroups
     const int g = lane / TEAM, tl = lane % TEAM;
@@ -1217,10 +1218,11 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
                 uint8_t *dst = lds + (uint32_t)gg * pitch;
                 const uint8_t *src = base + og;
                 const uint32_t nch = ((uint32_t)Lg + 15u) >> 4;
+                const bool all_inside = og + 16u * nch <= batch_end; // wave-uniform: no chunk of this read can leave the batch
                 for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
                     const uint32_t so = 16u * (c0 + (uint32_t)lane);
                     if (c0 + (uint32_t)lane < nch) {
-                        if (og + so + 16u <= batch_end) {
+                        if (all_inside || og + so + 16u <= batch_end) {
                             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + c0 * 16u), 16, 0, SK_DMA_AUX);
                         } else { // the batch ends inside this chunk: byte by byte
                             for (uint32_t j = 0; j < 16u && og + so + j < batch_end; ++j) dst[so + j] = src[so + j];
@@ -1238,12 +1240,97 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         if (w == 0) w = L; // trim.cpp:30
         const int nwin = scan ? L - w + 1 : 0;
         const int T = a.craw * w;
-        // this lane's chunk of the read
-        const int c4 = scan ? ((((L + TEAM - 1) / TEAM + 3) >> 2) | 1) : 1;
+        // this lane's chunk of the read: c bytes, c/4 odd (conflict-free dword walks); SKIP: c/16 odd
+        // (conflict-free 16-byte walks)
+        const int c4 = !scan ? 1 : SKIP ? 4 * (((((L + TEAM - 1) / TEAM) + 15) >> 4) | 1) : ((((L + TEAM - 1) / TEAM + 3) >> 2) | 1);
         const int c = 4 * c4;
         const int s = tl * c;
         const int sdw = s >> 2;
 
+        const bool has_win = scan && s < nwin;
+        const int we = min(s + c, nwin); // this lane's windows: [s, we)
+        uint32_t fa = NONE, fb = NONE, fc = NONE; // first >= T, first < T, first < T after fa (window indices)
+        bool bad = false;
+        if (SKIP) {
+            // ---- whole-wave teams (long reads): prefix sums + skip-ahead instead of walking every window.
+            // P16[k] = sum of the read's bytes before position 16k, so S_i = P(i + w) - P(i) for ANY i costs two
+            // table reads and two partial 16-byte sums; and since one step changes a window sum by at most 255,
+            // a lane at S_i - T = v < 0 can jump ceil(-v / 255) windows ahead without missing the first
+            // S >= T (and v / 255 + 1 ahead when looking for the first S < T).  Window sums of long reads sit
+            // far from the threshold almost everywhere (w * |Q - q|), so a lane evaluates a few dozen windows
+            // instead of its whole chunk: 6 instead of 48 VALU per dword of the read, exact for every input.
+            uint32_t *P16 = reinterpret_cast<uint32_t *>(lds + rbuf);
+            const sk_v4u *row128 = reinterpret_cast<const sk_v4u *>(rowb);
+            const int sg = s >> 4;
+            const int ngroups = scan ? max(0, min(c4 >> 2, (L - s + 15) >> 4)) : 0;
+            uint32_t sad = 0, run = 0;
+            for (int gi = 0; gi < ngroups; ++gi) { // 1. range check (trim.cpp:129) + local prefix of the chunk
+                const sk_v4u x = row128[sg + gi];
+                const int nval = L - (s + 16 * gi);
+                P16[sg + gi] = run;
+                if (nval >= 16) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        sad = __builtin_amdgcn_sad_u8(x[u], min4, sad);
+                        sad = __builtin_amdgcn_sad_u8(x[u], max4, sad);
+                        run = __builtin_amdgcn_sad_u8(x[u], 0u, run);
+                    }
+                } else { // the read ends inside this group
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t xq = first_bytes(x[u], nval - 4 * u, min4);
+                        sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+                        sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+                        run = __builtin_amdgcn_sad_u8(first_bytes(x[u], nval - 4 * u, 0u), 0u, run);
+                    }
+                }
+            }
+            bad = scan && sad != (uint32_t)(16 * ngroups * range); // fillers are legal chars
+            const uint32_t incl = team_scan_add<TEAM>(run, tl);
+            const uint32_t excl = incl - run;
+            for (int gi = 0; gi < ngroups; ++gi) atomicAdd(&P16[sg + gi], excl); // local -> global prefix (ds_add_u32)
+            // P(L) when L is a multiple of 16: one entry past the last group
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tl == 0 && scan) P16[(L + 15) >> 4] = total;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto P = [&](int x) -> int { // sum of the bytes before position x, 0 <= x <= L
+                const int gi = x >> 4, r = x & 15;
+                uint32_t p = P16[gi];
+                const sk_v4u d = row128[gi];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) p = __builtin_amdgcn_sad_u8(first_bytes(d[u], r - 4 * u, 0u), 0u, p);
+                return (int)p;
+            };
+            auto SmT = [&](int i) -> int { return P(i + w) - P(i) - T; }; // sign bit <=> window average below the threshold
+            if (has_win) { // 2./3. trim.cpp:34-81: at most two searches per lane
+                int j = s, v = SmT(s);
+                if (v >= 0) {
+                    fa = (uint32_t)s;
+                    for (;;) { // the first window below the threshold after it
+                        j += v / 255 + 1;
+                        if (j >= we) break;
+                        v = SmT(j);
+                        if (v < 0) { fb = fc = (uint32_t)j; break; }
+                    }
+                } else {
+                    fb = (uint32_t)s;
+                    for (;;) { // the first window at or above the threshold
+                        j += (-v + 254) / 255;
+                        if (j >= we) break;
+                        v = SmT(j);
+                        if (v >= 0) { fa = (uint32_t)j; break; }
+                    }
+                    if (fa != NONE) {
+                        for (;;) { // and the first one below it again
+                            j += v / 255 + 1;
+                            if (j >= we) break;
+                            v = SmT(j);
+                            if (v < 0) { fc = (uint32_t)j; break; }
+                        }
+                    }
+                }
+            }
+        } else {
         // ---- 1. range check + chunk sum (trim.cpp:129 and the prefix of 31-33)
         uint32_t sad = 0, csum = 0;
         {
@@ -1275,11 +1362,10 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             }
         }
         // every dword visited contributes 4 * range when clean (fillers are legal chars)
-        const bool bad = scan && sad != (uint32_t)(4 * c4 * range);
+        bad = scan && sad != (uint32_t)(4 * c4 * range);
         const uint32_t incl = team_scan_add<TEAM>(csum, tl);
 
         // ---- 2. S_s - T for this lane's first window: P(s + w) - P(s) - T
-        const bool has_win = scan && s < nwin;
         const int dq = w / c, rem = w - dq * c;
         const int kq = tl + dq; // the chunk position s + w lies in
         const uint32_t below = (uint32_t)__shfl((int)incl, g * TEAM + min(max(kq - 1, 0), TEAM - 1), 64);
@@ -1293,8 +1379,6 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         int v = (int)((kq >= 1 ? below : 0u) + part) - (int)(incl - csum) - T; // sign bit <=> window average below the threshold
 
         // ---- 3. the lane's windows [s, we), 32 per trip: trim.cpp:34-81 without the breaks
-        const int we = min(s + c, nwin);
-        uint32_t fa = NONE, fb = NONE, fc = NONE; // first >= T, first < T, first < T after fa (window indices)
         {
             const int mytrips = has_win ? (we - s + 31) >> 5 : 0;
             const int tripmax = __builtin_amdgcn_readfirstlane(wave_max(mytrips));
@@ -1338,6 +1422,8 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             }
         }
 
+        }
+
         // ---- 4. the team's windows: trim.cpp:42 and :61
         const int fai = fa == NONE ? INF : (int)fa, fbi = fb == NONE ? INF : (int)fb, fci = fc == NONE ? INF : (int)fc;
         const int i0 = a.no5 ? INF : team_min<TEAM>(fai);
@@ -1378,7 +1464,7 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         if (__builtin_amdgcn_ballot_w64(bad)) {
             int pb = INF;
             if (bad) {
-                for (int k = 0; k < c4 && pb == INF; ++k) {
+                for (int k = 0; k < c4 && s + 4 * k < L && pb == INF; ++k) {
                     const uint32_t f = keep_first(bad_flags(row32[sdw + k], min4, hi4), L - (s + 4 * k));
                     if (f) pb = s + 4 * k + (__builtin_ctz(f) >> 3);
                 }
@@ -1395,7 +1481,7 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             uint32_t nlo = NONE, anyN = 0; // bit index of the first lowercase n; any uppercase N
             const int c4m = __builtin_amdgcn_readfirstlane(wave_max(scan ? c4 : 0));
             for (int k = 0; k < c4m; ++k) {
-                if (scan && k < c4) {
+                if (scan && k < c4 && s + 4 * k < L) {
                     const uint32_t x = first_bytes(row32[sdw + k], L - (s + 4 * k), 0u);
                     const uint32_t y = (x | 0x20202020u) ^ 0x6e6e6e6eu;
                     const uint32_t either = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & H4;
@@ -1437,6 +1523,8 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         if (*reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
         // slots (not tiles) are dealt to the waves, so that the reads of one left-over tile spread over the
         // device; each wave asks the question for the tile its slot lies in (again only when the tile changes)
+        // (a fixed deal: a ticket counter in global memory, one atomic per read, measured slower -- 0.82 against
+        // 0.69 ms on 64 200 reads of 1-30 kb -- although the fixed deal leaves the slowest wave behind)
         uint64_t asked = ~0ull;
         bool fits = false;
         for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
@@ -1712,7 +1800,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const
     at.team_maxlen = (uint32_t)cap;
     // what the lead stream and the 32-window trips may read past the read: a chunk + 32 windows + slack
     at.team_rbuf = (uint32_t)((cap + cap / team + 4 + 32 + SK_TILE_SLACK + 15) & ~(uint64_t)15);
-    const uint32_t lds_bytes = (uint32_t)rpw * (at.team_rbuf + 80u);
+    // whole-wave teams keep a prefix table beside the read: 4 bytes per 16 (sk_scan_team_kernel, SKIP)
+    const uint32_t lds_bytes = (uint32_t)rpw * (at.team_rbuf + 80u) + (team == 64 ? (at.team_rbuf >> 2) + 64u : 0u);
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
     if (per_cu > 16) per_cu = 16;
     if (per_cu < 1) return hipErrorInvalidValue;

@@ -476,3 +476,49 @@ def test_misaligned_base_pointers_and_odd_strides(sk_ctx):
                 got = out.cpu().numpy()
                 bad = np.nonzero((got != want).any(axis=1))[0]
                 assert bad.size == 0, (stride, shift_q, shift_s, tn, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+def test_long_reads_hovering_at_the_threshold(sk_ctx):
+    """The skip-ahead window search of the whole-wave general kernel (prefix table, jumps of |S - T| / 255 windows)
+    on reads built to defeat it: window averages that sit ON the threshold for thousands of windows (chars
+    alternating around it, slow sawtooth drifts, single-char spikes of 126 and 33 that move a window sum by the
+    largest legal step), lengths across the team-of-16 / whole-wave boundary and up to 40 kb, with -x and -n."""
+    rng = np.random.default_rng(77)
+    lens = np.array([4095, 4096, 4097, 5000, 8191, 12_345, 20_000, 40_000] * 3, dtype=np.uint32)
+    n = len(lens)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    tot = int(offs[-1])
+    thr = 33 + 20
+    qual = np.empty(tot, dtype=np.uint8)
+    for i in range(n):
+        a, b = int(offs[i]), int(offs[i + 1])
+        L = b - a
+        k = np.arange(L)
+        mode = i % 3
+        if mode == 0:    # alternate thr-1 / thr+1 (average exactly thr over even windows), random flips
+            q = thr + np.where(k % 2 == 0, -1, 1) + (rng.random(L) < 0.02) * rng.choice([-1, 1], L)
+        elif mode == 1:  # sawtooth of the window average through the threshold, period ~ 3 windows
+            w = max(1, L // 10)
+            q = thr + np.round(2.5 * np.sin(2 * np.pi * k / (3.1 * w))).astype(int)
+        else:            # flat at the threshold with rare extreme chars
+            q = np.full(L, thr)
+            hits = rng.random(L) < 0.001
+            q = np.where(hits, rng.choice([33, 126], L), q)
+        qual[a:b] = np.clip(q, 33, 126)
+    seq = rng.choice(np.frombuffer(b"ACGT" * 500 + b"Nn", dtype=np.uint8), size=tot)
+    for q, l, x, tn in ((20, 20, 0, 0), (20, 1000, 1, 0), (21, 0, 0, 1), (19, 20, 0, 0)):
+        p, po = both_params("sanger", q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=4)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offs)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+        # and each length as a uniform fixed-stride batch of its own (the all-reads mode of the kernel)
+    for L in (4097, 12_345):
+        m = 40
+        qm = np.clip(thr + rng.integers(-1, 2, size=(m, L)), 33, 126).astype(np.uint8)
+        p, po = both_params("sanger", 20, 20, 0, 0)
+        want, _ = ob.oracle_trim_batch(po, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
+        got = sk_ctx.trim_batch(p, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
+        assert (got == want).all(), L
