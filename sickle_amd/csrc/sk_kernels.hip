@@ -1803,7 +1803,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const
     // whole-wave teams keep a prefix table beside the read: 4 bytes per 16 (sk_scan_team_kernel, SKIP)
     const uint32_t lds_bytes = (uint32_t)rpw * (at.team_rbuf + 80u) + (team == 64 ? (at.team_rbuf >> 2) + 64u : 0u);
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    if (per_cu > 16) per_cu = 16;
+    static const int wave_cap = [] { const char *e = getenv("SK_TEAM_WAVES"); return e ? atoi(e) : 16; }();
+    if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) return hipErrorInvalidValue;
     const uint64_t n_slots = (a->n_reads + rpw - 1) / rpw;
     uint64_t grid = (uint64_t)cu_count * per_cu;
