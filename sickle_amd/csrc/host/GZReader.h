@@ -22,6 +22,7 @@
 #ifndef SICKLE_GZREADER_H
 #define SICKLE_GZREADER_H
 
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include "Deflate.h"
@@ -41,6 +42,18 @@ public:
     ~RawBuf()
     {
         if (!borrowed) free(p);
+        else drop_view_pages();
+    }
+    // A consumed view of the mapped input hands its page-table entries back now (the pages stay in the page
+    // cache; a neighbouring view that shares a boundary page simply faults it in again).  Otherwise the whole
+    // multi-gigabyte mapping is torn down by the kernel at process exit, serially, while the caller waits:
+    // measured on one box, interleaved, 20 M reads: 1.36-1.44 s without, 1.13-1.16 s with (tools/probes/extern_time.sh).
+    void drop_view_pages()
+    {
+        if (n < (1u << 20)) return;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + 4095) & ~(uintptr_t)4095;
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + n) & ~(uintptr_t)4095;
+        if (hi > lo) madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED);
     }
     char *data() { return p; }
     const char *data() const { return p; }

@@ -276,6 +276,9 @@ int Abstract_Trimmer::open_device()
                 fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
                         device_ids[g], rc);
                 ctxs[g] = nullptr;
+                std::lock_guard<std::mutex> lk(open_lock);
+                open_failed = open_done = true;
+                open_cv.notify_all();
                 return;
             }
         }
@@ -284,9 +287,15 @@ int Abstract_Trimmer::open_device()
         // bytes of text per input file; quality is under half of it.  Too small only means a
         // later grow().
         const size_t text = (size_t)batch_len * (size_t)staging_files;
-        for (size_t i = 0; i < slots.size(); ++i)
+        for (size_t i = 0; i < slots.size(); ++i) {
             grow(ctx_of((int)i), slots[i], text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0);
-        devices_ok = true;
+            std::lock_guard<std::mutex> lk(open_lock);
+            slots_ready = (int)i + 1;
+            open_cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(open_lock);
+        devices_ok = open_done = true;
+        open_cv.notify_all();
     });
     return 0;
 }
@@ -295,6 +304,13 @@ void Abstract_Trimmer::ensure_device()
 {
     if (device_opener.joinable()) device_opener.join();
     if (!devices_ok) fatal_exit(EXIT_FAILURE); // the opener has printed why
+}
+
+void Abstract_Trimmer::ensure_slot(int slot)
+{
+    std::unique_lock<std::mutex> lk(open_lock);
+    open_cv.wait(lk, [&] { return open_done || slots_ready > slot; });
+    if (open_failed) fatal_exit(EXIT_FAILURE); // the opener has printed why
 }
 
 void Abstract_Trimmer::close_device()
@@ -352,7 +368,7 @@ void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bo
 
 void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
 {
-    ensure_device();
+    ensure_slot(slot);
     Slot &s = slots[(size_t)slot];
     sk_ctx *ctx = ctx_of(slot);
     const int dev_slot = slot / (int)ctxs.size();
