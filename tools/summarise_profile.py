@@ -35,10 +35,13 @@ shutil.copyfile(os.path.join(src, "trace_bench.json"), os.path.join(dst, "%s_ben
 # timed launches are the last `steps` of the trace
 trace = glob.glob(os.path.join(src, "trace/*/*kernel_trace.csv"))
 if trace:
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace[0])) if "sk_scan" in r["Kernel_Name"]]
     line = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+    # the headline kernel only (the default bench run also launches every variant's kernels): the name the
+    # counter passes saw most often
+    head = name.split("(")[0] if name else "sk_scan"
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace[0])) if r["Kernel_Name"].startswith(head)]
     k = line["steps"]
-    json.dump({"kernel_launches_in_trace": len(d), "avg_ms_all_launches": sum(d) / len(d), "timed_steps": k,
+    json.dump({"kernel": head, "kernel_launches_in_trace": len(d), "avg_ms_all_launches": sum(d) / len(d), "timed_steps": k,
                "avg_ms_timed_launches": sum(d[-k:]) / k, "bench_events_avg_ms_same_run": line["roofline"]["kernel_ms_avg"]},
               open(os.path.join(dst, "%s_timed_launches.json" % tag), "w"), indent=1)
     print("trace: all %d launches avg %.4f ms, the %d timed ones %.4f ms, bench events %.4f ms" %
