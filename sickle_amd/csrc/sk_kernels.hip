@@ -1191,19 +1191,28 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     const uint32_t cthr4 = splat((uint32_t)a.cthr);
     const int range = a.qmax - a.qmin;
 
-    auto do_slot = [&](uint64_t slot) {
+    // known = the caller already holds this lane's read (start, length): the hand-over mode took them from the
+    // tile probe; otherwise they are loaded here
+    auto do_slot = [&](uint64_t slot, bool known, uint64_t o_known, int L_known) {
         const uint64_t r = slot * RPW + g;
         const bool valid = r < a.n_reads;
-        const uint64_t rc = min(r, a.n_reads - 1);
-        uint64_t o, e;
-        if (offsets) {
-            o = offsets[rc];
-            e = offsets[rc + 1];
+        uint64_t o;
+        int L;
+        if (known) {
+            o = o_known;
+            L = valid ? L_known : 0;
         } else {
-            o = rc * a.stride;
-            e = o + (lengths ? lengths[rc] : a.read_len);
+            const uint64_t rc = min(r, a.n_reads - 1);
+            uint64_t e;
+            if (offsets) {
+                o = offsets[rc];
+                e = offsets[rc + 1];
+            } else {
+                o = rc * a.stride;
+                e = o + (lengths ? lengths[rc] : a.read_len);
+            }
+            L = (valid && e >= o) ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
         }
-        const int L = (valid && e >= o) ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
         const bool big = L > (int)a.team_maxlen; // not through LDS
         const bool scan = L > 0 && L >= a.lthr && !big; // trim.cpp:21
 
@@ -1521,22 +1530,25 @@ sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
         // only the 64-read tiles sk_scan_tile_any_kernel left (the same test as there) -- if it left any:
         // it has put this scan's number into the word after the error word for every tile it skipped
         if (*reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
-        // slots (not tiles) are dealt to the waves, so that the reads of one left-over tile spread over the
-        // device; each wave asks the question for the tile its slot lies in (again only when the tile changes)
-        // (a fixed deal: a ticket counter in global memory, one atomic per read, measured slower -- 0.82 against
-        // 0.69 ms on 64 200 reads of 1-30 kb -- although the fixed deal leaves the slowest wave behind)
-        uint64_t asked = ~0ull;
-        bool fits = false;
-        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
-            const uint64_t grp = (slot * RPW) >> 6;
-            if (grp != asked) {
-                fits = rag_tile_fits(rag_probe(grp, lane, offsets, lengths, a), a.buf_bytes);
-                asked = grp;
+        // Runs of 8 consecutive reads are dealt to the waves (so that the reads of one left-over tile spread
+        // over the device).  A wave asks the question for the tile its run lies in; the probe leaves read
+        // 64*tile + l's start and length in lane l, so the run's reads need no further offset loads.
+        // (A ticket counter in global memory instead of the fixed deal, one atomic per read, measured slower:
+        // 0.82 against 0.69 ms on 64 200 reads of 1-30 kb.)
+        constexpr uint64_t RUN = 8;
+        const uint64_t n_runs = (a.n_reads + RUN - 1) / RUN;
+        for (uint64_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+            const sk_rag_tile pr = rag_probe((run * RUN) >> 6, lane, offsets, lengths, a);
+            if (rag_tile_fits(pr, a.buf_bytes)) continue;
+            for (uint64_t slot = run * RUN / RPW; slot < (run + 1) * RUN / RPW && slot < n_slots; ++slot) {
+                const int idx = (int)((slot * RPW + (uint64_t)g) & 63u); // this lane's read within the tile
+                const uint32_t ro = (uint32_t)__shfl((int)pr.rowoff, idx, 64);
+                const int len = __shfl(pr.len, idx, 64);
+                do_slot(slot, true, pr.start + ro, len);
             }
-            if (!fits) do_slot(slot);
         }
     } else {
-        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) do_slot(slot);
+        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) do_slot(slot, false, 0, 0);
     }
 }
 

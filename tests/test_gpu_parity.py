@@ -216,6 +216,19 @@ def test_empty_and_tiny_batches(sk_ctx):
         want, _ = ob.oracle_trim_batch(ob.make_params("sanger"), synth.pack_fixed(qual, 152), stride=152, read_len=150, n_reads=n)
         got = sk_ctx.trim_batch(p, synth.pack_fixed(qual, 152), stride=152, read_len=150, n_reads=n)
         assert (got == want).all()
+        # the same reads packed back to back and as a ragged batch (re-strided tiles: partial last tile,
+        # the last chunks of the buffer copied byte by byte)
+        got = sk_ctx.trim_batch(p, qual.reshape(-1), stride=150, read_len=150, n_reads=n)
+        assert (got == want).all(), ("packed", n)
+        offs = (np.arange(n + 1, dtype=np.uint64) * 150)
+        got = sk_ctx.trim_batch(p, qual.reshape(-1), offsets=offs)
+        assert (got == want).all(), ("ragged", n)
+    # ragged batches of empty and one-byte reads
+    offs = np.array([0, 0, 1, 1, 2, 5, 5], dtype=np.uint64)
+    q = np.array([70, 40, 70, 70, 70], dtype=np.uint8)
+    want, _ = ob.oracle_trim_batch(ob.make_params("sanger", 20, 0), q, offsets=offs)
+    got = sk_ctx.trim_batch(capi.make_params("sanger", 20, 0), q, offsets=offs)
+    assert (got == want).all(), (got, want)
 
 
 def test_async_slots_overlap(sk_ctx):
