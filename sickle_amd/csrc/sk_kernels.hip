@@ -13,190 +13,26 @@
 // char lies in the part of the read the reference would have touched: [0, i1 + w) if the
 // 3' break fired, the whole read otherwise, nothing if L < length_threshold.
 //
-// Two kernels:
-//   sk_scan_tile_kernel   fixed-stride batches.  One LANE per read, one wavefront per 64-read
-//                         tile, 16 single-wave workgroups per CU.  The tile (64*stride contiguous
-//                         bytes) goes HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, nt policy:
-//                         coalesced, no VGPR round trip).  Uniform-length batches take their window
-//                         sums from the integer matrix pipe (band(w) x Q as two
-//                         v_mfma_i32_32x32x32_i8 per 32 windows x 32 reads, the B operand read
-//                         straight out of the LDS rows) and spend one v_alignbit per window on the
-//                         vector ALU to collect the signs of S_i - T; mixed-length batches walk
-//                         their rows 4 windows per dword with byte-parallel arithmetic
-//                         (v_alignbyte, signed byte differences, v_dot4_i32_i8, v_alignbit).
-//                         Range check: two v_sad_u8 per dword.
-//   sk_scan_team_kernel   any layout (ragged offsets, odd strides, long reads).  One
-//                         WAVEFRONT per read; each lane owns a contiguous run of windows,
-//                         seeds its window sum directly and rolls it in a register; the
-//                         per-lane first-hits are combined with wave min-reductions.
+// The kernels, by translation unit:
+//   sk_kernels.hip (this file)  the LANE-per-read tile kernels.  One wavefront per 64-read tile, single-wave
+//                         workgroups, up to 16 per CU.  The tile goes HBM -> LDS with global_load_lds_dwordx4
+//                         (LDS-DMA, nt policy: coalesced, no VGPR round trip), through the wave's registers
+//                         (sk_scan_tile_staged_kernel: rows of 72..160 bytes), or RE-STRIDED by a per-lane
+//                         source address (sk_scan_tile_any_kernel: packed and ragged batches).  Uniform-length
+//                         tiles take their window sums from the integer matrix pipe (band(w) x Q as two
+//                         v_mfma_i32_32x32x32_i8 per 32 windows x 32 reads, the B operand read straight out of
+//                         the LDS rows) and spend one v_alignbit per window on the vector ALU to collect the
+//                         signs of S_i - T; mixed-length tiles walk their rows 4 windows per dword with
+//                         byte-parallel arithmetic (v_alignbyte, signed byte differences, v_dot4_i32_i8,
+//                         v_alignbit).  Range check: two v_sad_u8 per dword.
+//   sk_team.hip           the general kernel: a TEAM of 16 lanes or the whole wave per read, the read staged
+//                         whole into LDS; long reads, whatever the lane-per-read tiles cannot hold.
+//   sk_aux.hip            read-bandwidth probe, pair classification.
+//   sk_kernel_common.h    what they share (byte-parallel helpers, DPP reductions, the ragged-tile probe ...).
 // HBM-bound byte streaming (algorithmic bytes: L + 8 per read, 2L + 8 with -n); the MFMAs are a
 // way to take instructions off the vector ALU, not the bound.
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include <map>
-#include <mutex>
-#include <utility>
-
-#include "sk_device.h"
-
-namespace {
-
-constexpr uint32_t H4 = 0x80808080u;
-constexpr int INF = 0x7fffffff;
-
-__device__ __forceinline__ uint32_t splat(uint32_t b) { return b * 0x01010101u; }
-
-// bit 7 of each byte set iff that byte (assumed < 128) is >= the byte of c4 (each <= 128)
-__device__ __forceinline__ uint32_t ge_flags(uint32_t x, uint32_t c4) { return ((x | H4) - c4) & H4; }
-
-// bit 7 of each byte set iff that byte is outside [min, max] (or >= 128):  the range check of
-// reference src/trim.cpp:129, four chars at a time.  min4 = splat(min), hi4 = splat(127 - max).
-__device__ __forceinline__ uint32_t bad_flags(uint32_t x, uint32_t min4, uint32_t hi4)
-{
-    uint32_t lo_ok = (x | H4) - min4;  // bit7 set iff byte >= min
-    uint32_t hi_bad = (x & ~H4) + hi4; // bit7 set iff (byte & 127) > max
-    return (~lo_ok | hi_bad | x) & H4;
-}
-
-// the first n bytes of x (n <= 0: none, n >= 4: all), the others taken from `filler`
-__device__ __forceinline__ uint32_t first_bytes(uint32_t x, int n, uint32_t filler)
-{
-    const uint32_t keep = n >= 4 ? ~0u : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
-    return (x & keep) | (filler & ~keep);
-}
-
-// flags of bytes [n, 4) cleared, n in 0..4
-__device__ __forceinline__ uint32_t keep_first(uint32_t flags, int n)
-{
-    return n >= 4 ? flags : (n <= 0 ? 0u : flags & ((1u << (8 * n)) - 1u));
-}
-
-// v_ffbh_u32 / v_ffbl_b32: index of the first set bit from the top / from the bottom, and
-// 0xFFFFFFFF for an empty mask (what __builtin_clz/ctz leave undefined and would guard with an
-// extra instruction).  Combined with saturating adds, "no hit" stays 0xFFFFFFFF through a min().
-__device__ __forceinline__ uint32_t ffbh_or_none(uint32_t x)
-{
-    uint32_t r;
-    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ uint32_t ffbl_or_none(uint32_t x)
-{
-    uint32_t r;
-    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-constexpr uint32_t NONE = 0xffffffffu;
-
-// ---- reductions on the data-parallel-primitive path (v_*_dpp: a lane reads its neighbour's register in the
-// same instruction, no LDS crossbar, no wait): four steps leave the result of each ROW of 16 lanes in all of
-// its lanes; the four rows are then combined through scalar registers (v_readlane + s_min/s_max).
-constexpr int DPP_QUAD_SWAP1 = 0xB1;  // quad_perm:[1,0,3,2]
-constexpr int DPP_QUAD_SWAP2 = 0x4E;  // quad_perm:[2,3,0,1]
-constexpr int DPP_ROW_HALF_MIRROR = 0x141;
-constexpr int DPP_ROW_MIRROR = 0x140;
-template <int CTRL>
-__device__ __forceinline__ int dpp_peer(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int row_min(int v) // min over the 16-lane row, in every lane of the row
-{
-    v = min(v, dpp_peer<DPP_QUAD_SWAP1>(v));
-    v = min(v, dpp_peer<DPP_QUAD_SWAP2>(v));
-    v = min(v, dpp_peer<DPP_ROW_HALF_MIRROR>(v));
-    v = min(v, dpp_peer<DPP_ROW_MIRROR>(v));
-    return v;
-}
-__device__ __forceinline__ int row_max(int v)
-{
-    v = max(v, dpp_peer<DPP_QUAD_SWAP1>(v));
-    v = max(v, dpp_peer<DPP_QUAD_SWAP2>(v));
-    v = max(v, dpp_peer<DPP_ROW_HALF_MIRROR>(v));
-    v = max(v, dpp_peer<DPP_ROW_MIRROR>(v));
-    return v;
-}
-__device__ __forceinline__ uint32_t row_or(uint32_t v)
-{
-    v |= (uint32_t)dpp_peer<DPP_QUAD_SWAP1>((int)v);
-    v |= (uint32_t)dpp_peer<DPP_QUAD_SWAP2>((int)v);
-    v |= (uint32_t)dpp_peer<DPP_ROW_HALF_MIRROR>((int)v);
-    v |= (uint32_t)dpp_peer<DPP_ROW_MIRROR>((int)v);
-    return v;
-}
-// wave-wide: one value per wave, in scalar registers
-__device__ __forceinline__ int wave_min(int v)
-{
-    v = row_min(v);
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int wave_max(int v)
-{
-    v = row_max(v);
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_or(uint32_t v)
-{
-    v = row_or(v);
-    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
-                      __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
-}
-
-__device__ __forceinline__ void report_error(unsigned long long *errword, uint64_t read, int pos, int ch)
-{
-    // lowest read index wins; ties (same read) resolve to the lowest position
-    unsigned long long key = ((unsigned long long)read << 32) | ((unsigned long long)(uint32_t)pos << 8) |
-                             (unsigned long long)(uint32_t)(ch & 0xff);
-    atomicMin(errword, key);
-}
-
-// cache policy of the tile DMA (the aux operand of global_load_lds): 0 = default, 2 = nt.
-// Every tile byte is read exactly once, so nt: measured -9 % on the DMA-only floor and -8 % on the
-// whole kernel against the default policy (interleaved A/B on one device, tools/ablate.py).
-#ifndef SK_TAIL_PRIO
-#define SK_TAIL_PRIO 0
-#endif
-#ifndef SK_DMA_AUX
-#define SK_DMA_AUX 2
-#endif
-using gptr_t = const __attribute__((address_space(1))) void *;
-using lptr_t = __attribute__((address_space(3))) void *;
-
-// Copies `bytes` (multiple of 4, wave-uniform) from global `src` (16-byte aligned) to the
-// wave-private LDS region `dst` with LDS-DMA; the LDS image is byte-identical to the global one.
-// Full 1 KiB pieces are issued four per trip through the instruction's immediate offset (it
-// moves the global and the LDS address together), without touching EXEC; only the last, partial
-// piece is predicated.
-__device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, uint32_t bytes, int lane)
-{
-    const uint32_t nfull = bytes >> 4;  // 16-byte chunks
-    const uint32_t pieces = nfull >> 6; // full 64-lane pieces
-    const uint8_t *sp = src + (size_t)lane * 16;
-    uint32_t p = 0;
-    for (; p + 4 <= pieces; p += 4) {
-        gptr_t g = (gptr_t)(sp + (size_t)p * 1024);
-        lptr_t l = (lptr_t)(dst + p * 1024);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 0, SK_DMA_AUX);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, SK_DMA_AUX);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, SK_DMA_AUX);
-        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, SK_DMA_AUX);
-    }
-    for (; p < pieces; ++p)
-        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, SK_DMA_AUX);
-    if ((uint32_t)lane < (nfull & 63u))
-        __builtin_amdgcn_global_load_lds((gptr_t)(sp + (size_t)p * 1024), (lptr_t)(dst + p * 1024), 16, 0, SK_DMA_AUX);
-    const uint32_t tail = (bytes & 15u) >> 2; // 0..3 dwords after the last full 16-byte chunk
-    if ((uint32_t)lane < tail)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)nfull * 16 + lane * 4), (lptr_t)(dst + nfull * 16),
-                                         4, 0, 0);
-}
-
-} // namespace
+#include "sk_kernel_common.h"
 
 // ------------------------------------------------------------------------------------------
 // Tiled kernel: lane per read, software-pipelined.
@@ -210,42 +46,8 @@ __device__ __forceinline__ void tile_to_lds(const uint8_t *src, uint8_t *dst, ui
 // to stay outstanding.  With -n the sequence tile of the same reads rides the same two
 // buffers: Q(t) -> buf0, S(t) -> buf1, Q(t+1) -> buf0, ...
 // ------------------------------------------------------------------------------------------
-namespace {
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_imm()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// s_waitcnt takes an immediate; n is wave-uniform and small (pieces of one tile + 1)
-__device__ __forceinline__ void wait_vmcnt(int n)
-{
-    switch (n) {
-#define SK_CASE(N) case N: wait_vmcnt_imm<N>(); break;
-        SK_CASE(0) SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7)
-        SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15)
-        SK_CASE(16) SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22) SK_CASE(23)
-        SK_CASE(24) SK_CASE(25) SK_CASE(26) SK_CASE(27) SK_CASE(28) SK_CASE(29) SK_CASE(30) SK_CASE(31)
-        SK_CASE(32) SK_CASE(33) SK_CASE(34)
-#undef SK_CASE
-    default: wait_vmcnt_imm<0>(); break;
-    }
-}
-
-// number of vector-memory instructions tile_to_lds issues for `bytes`
-__device__ __forceinline__ int tile_pieces(uint32_t bytes)
-{
-    return (int)(((bytes >> 4) + 63) >> 6) + (((bytes & 15u) >> 2) ? 1 : 0);
-}
-
-} // namespace
-
 #define SK_STAGE_MIN 5  /* register-staged kernels exist for tiles of 5..10 KiB: row strides 72..160 */
 #define SK_STAGE_MAX 10
-typedef int sk_v4i __attribute__((ext_vector_type(4)));
-typedef int sk_v16i __attribute__((ext_vector_type(16)));
-typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 
 // MFMA = true (uniform-length batches; w <= 65, i.e. every uniform length the tiled kernel takes):
 // the window sums are taken off the vector ALU.  A box filter is a banded 0/1 matrix, so for 32 windows x 32 reads
@@ -278,105 +80,6 @@ typedef unsigned sk_v2u __attribute__((ext_vector_type(2)));
 // image as the DMA's) once the scan is over.  Plain loads stream faster than LDS-DMA on this
 // device (tools/probes/read_bw.hip: 7.0 against 6.5 TB/s), and the registers act as a second
 // buffer per wave without costing LDS.
-typedef unsigned sk_v4u __attribute__((ext_vector_type(4)));
-
-namespace {
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// row pitch of the LDS image the re-striding loader builds for reads of up to `len` bytes.  The loader
-// moves 16 bytes per lane, so a multiple of 16, with an ODD number of 16-byte units: the rows' 8-byte
-// reads (matrix path) then fall two lanes to a bank pair and their 4-byte reads (vector-ALU path) four
-// lanes to a bank -- the best 16-byte granules allow (SQ_LDS_BANK_CONFLICT is 56 % of the LDS cycles on
-// packed 150 bp).  Measured alternative: 4 bytes per lane and a pitch of 8 * odd (no conflicts, four
-// times the DMA instructions) is slower everywhere -- packed 150 bp 0.44 against 0.33 ms, ragged 150 bp
-// 0.56 against 0.42 ms, a 75-301 bp mix 0.59 against 0.46 ms: the loader's instruction count costs
-// more than the conflicts.
-template <bool UNIFORM>
-__device__ __forceinline__ uint32_t rag_pitch(uint32_t len)
-{
-    return 16u * (((len + 15u) >> 4) | 1u);
-}
-
-// one LDS-DMA of the re-striding loader: 16 bytes per lane (uniform lengths) or 4
-template <bool WIDE>
-__device__ __forceinline__ void dma_piece(const uint8_t *g, uint8_t *l)
-{
-    if (WIDE) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, SK_DMA_AUX);
-    else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, SK_DMA_AUX);
-}
-
-// One tile = reads [64t, 64t+64) of a batch whose rows start at any byte address (`offsets`, or a
-// fixed stride that is not a multiple of 8, with or without `lengths`), as its lanes see it
-struct sk_rag_tile {
-    uint64_t start;  // wave-uniform: byte offset of the tile's first read
-    uint32_t span;   // wave-uniform: bytes from there to the end of its last read (saturated)
-    uint32_t rowoff; // per lane: this lane's read starts at start + rowoff
-    int len;         // per lane: its length (0 for lanes past the end of the batch)
-    int lmax;        // wave-uniform: the longest of them
-};
-
-__device__ __forceinline__ sk_rag_tile rag_probe(uint64_t t, int lane, const uint64_t *__restrict__ offsets,
-                                                 const uint32_t *__restrict__ lengths, const sk_scan_args &a)
-{
-    const uint64_t r = (t << 6) + lane;
-    const uint64_t rc = min(r, a.n_reads - 1);
-    uint64_t o, e;
-    if (offsets) {
-        o = offsets[rc];
-        e = offsets[rc + 1];
-    } else {
-        o = rc * a.stride;
-        e = o + (lengths ? min(lengths[rc], a.stride) : a.read_len);
-    }
-    const int last = (int)min((uint64_t)63, a.n_reads - 1 - (t << 6));
-    sk_rag_tile g;
-    g.start = readlane_u64(o, 0);
-    const uint64_t end = readlane_u64(e, last);
-    const uint64_t span = end >= g.start ? end - g.start : ~0ull;
-    g.span = (uint32_t)min(span, (uint64_t)0xffffffffu);
-    // offsets that do not ascend give a read no bytes rather than bytes outside its tile
-    const bool ok = r < a.n_reads && o >= g.start && e >= o && e <= end;
-    g.rowoff = ok ? (uint32_t)(o - g.start) : 0u;
-    g.len = ok ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
-    g.lmax = wave_max(g.len);
-    return g;
-}
-
-// Is the tile sk_scan_tile_any_kernel's?  Its re-strided image (64 rows at rag_pitch(lmax)) must fit
-// the wave's LDS buffer.  sk_scan_team_kernel asks the same question and takes the other tiles.
-__device__ __forceinline__ bool rag_tile_fits(const sk_rag_tile &g, uint32_t buf_bytes)
-{
-    return g.lmax <= SK_RAG_MAX_LEN && 64u * rag_pitch<false>((uint32_t)g.lmax) + SK_TILE_SLACK <= buf_bytes;
-}
-
-// end of the batch's bytes (exclusive), for the test above
-__device__ __forceinline__ uint64_t rag_batch_end(const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
-                                                  const sk_scan_args &a)
-{
-    if (offsets) return offsets[a.n_reads];
-    return (a.n_reads - 1) * a.stride + (lengths ? min(lengths[a.n_reads - 1], a.stride) : a.read_len);
-}
-
-// what a wave needs to know about one tile
-struct sk_tile_view {
-    uint64_t off;    // wave-uniform: byte offset of the tile (of its first read) in qual / seq
-    uint32_t bytes;  // wave-uniform: bytes of the tile in global memory
-    uint32_t ts;     // wave-uniform: row pitch of its LDS image
-    uint32_t rows;   // wave-uniform: reads in it
-    int len;         // read length: one value when UNIFORM, per lane otherwise (0 past the end)
-    uint64_t r;      // per lane: where this lane's cut goes in out[]
-    uint32_t rowoff; // ragged: per lane, where the lane's read starts, relative to off
-    bool take;       // rows at any address: false = left to sk_scan_team_kernel
-    bool uni;        // ragged: the tile's 64 reads have one length (their rows are then len apart)
-};
-
-} // namespace
 
 // RAG (rows at any byte address: packed fixed-stride batches whose stride is not a multiple of 8 or
 // whose base is not 16-byte aligned, and ragged `offsets` batches): the tile is RE-STRIDED on its way
@@ -1028,561 +731,9 @@ sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------
-// General kernel: a TEAM of lanes per read (16 or 64), any layout, any length.
-//
-// Takes what the lane-per-read kernels cannot: rows too long for a 64-read LDS tile.  The reads of
-// a wave (4 with teams of 16, 1 with teams of 64) are staged whole into LDS by the entire wave --
-// 16 bytes per lane per LDS-DMA, source address per lane, so the image of each read starts on an
-// aligned boundary whatever its address in the batch.  Then lane tl of a team owns the c bytes
-// [tl*c, tl*c + c) of its read (c a multiple of 4 with c/4 odd: the lanes' dword walks spread over
-// the banks) and the windows that START there:
-//   1. range check (two v_sad_u8 per dword) and byte sum of its chunk; inclusive scan of the chunk
-//      sums over the team: P(x) for every chunk boundary x;
-//   2. S_s - T for its first window from the prefix: P(s + w) - P(s), the first taken from the lane
-//      w/c chunks up plus a partial chunk sum -- no lane adds up w bytes;
-//   3. the windows, 4 per dword of the trailing and the leading stream with byte-parallel arithmetic
-//      (the vector-ALU path of the tile kernel), 32 per trip: first >= T, first < T, first < T after
-//      the lane's first >= T;
-//   4. team min-reductions give i0 and i1; the two in-window searches and the N rule stride the
-//      team over dwords; lane 0 of the team stores the cut.
-// A read too long for the wave's LDS buffer is scanned straight from global memory by the whole
-// wave (scan_read_global: the same algorithm byte by byte; correctness path).
-// With a.buf_bytes != 0 the kernel takes only the 64-read tiles sk_scan_tile_any_kernel left.
-// ------------------------------------------------------------------------------------------
-namespace {
-
-template <int TEAM>
-__device__ __forceinline__ int team_min(int v) // teams of 16 lanes are DPP rows
-{
-    return TEAM == 16 ? row_min(v) : wave_min(v);
-}
-template <int TEAM>
-__device__ __forceinline__ uint32_t team_or(uint32_t v)
-{
-    return TEAM == 16 ? row_or(v) : wave_or(v);
-}
-template <int TEAM>
-__device__ __forceinline__ uint32_t team_scan_add(uint32_t v, int tl) // inclusive prefix sum over the team
-{
-    // within a row: row_shr:n reads the lane n to the left, lanes without one add nothing (bound_ctrl: 0)
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    if (TEAM == 64) { // the rows before this lane's: their totals through scalar registers
-        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
-                       t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
-        const int row = tl >> 4;
-        v += row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2;
-    }
-    return v;
-}
-
-// one read, the whole wave, from global memory: reference trim.cpp:3-116 with the closed form of this
-// file's header, byte by byte.  Returns the cut (the same value in every lane).
-template <bool HAS_SEQ>
-__device__ __forceinline__ sk_cut_dev scan_read_global(const uint8_t *__restrict__ q, const uint8_t *__restrict__ sq, int L,
-                                                    uint64_t r, int lane, const sk_scan_args &a, unsigned long long *errword)
-{
-    int five = -1, three = -1;
-    if (L > 0 && L >= a.lthr) { // trim.cpp:21
-        int w = L / 10;
-        if (w == 0) w = L;
-        const int nwin = L - w + 1;
-        const int T = a.craw * w;
-
-        // first bad char of the whole read (lanes stride the bytes, coalesced)
-        int pbad = INF;
-        for (int j = lane; j < L; j += 64) {
-            const int c = (int)(int8_t)q[j];
-            if ((c < a.qmin || c > a.qmax) && pbad == INF) pbad = j;
-        }
-        pbad = wave_min(pbad);
-
-        // lane owns windows [s, e): seeds the sum, then rolls it (trim.cpp:76-80)
-        const int per = (nwin + 63) >> 6;
-        const int s = lane * per;
-        const int e = min(nwin, s + per);
-        int fa = INF, fb = INF, fc = INF; // first >=T, first <T, first <T after fa
-        if (s < e) {
-            int tot = 0;
-            for (int j = 0; j < w; ++j) tot += q[s + j];
-            for (int i = s; i < e; ++i) {
-                if (tot >= T) {
-                    if (fa == INF) fa = i;
-                } else {
-                    if (fb == INF) fb = i;
-                    if (fa != INF && fc == INF) fc = i;
-                }
-                if (i + 1 < e) tot += (int)q[i + w] - (int)q[i];
-            }
-        }
-        const int i0 = a.no5 ? -1 : wave_min(fa);
-        const bool found5 = a.no5 || i0 != INF;
-        int cand = INF;
-        if (a.no5) cand = fb;
-        else if (i0 != INF && s < e) cand = (s > i0) ? fb : (fa == i0 ? fc : INF);
-        const int i1 = wave_min(cand);
-        const bool done = found5 && i1 != INF;
-
-        five = 0;
-        three = L;
-        if (!a.no5 && i0 != INF) { // trim.cpp:46-51
-            int hit = INF;
-            for (int j = lane; j < w && hit == INF; j += 64)
-                if ((int)q[i0 + j] >= a.cthr_raw) hit = i0 + j;
-            five = wave_min(hit);
-            if (five == INF) five = 0;
-        }
-        if (done) { // trim.cpp:65-70
-            int hit = INF;
-            for (int j = lane; j < w && hit == INF; j += 64)
-                if ((int)q[i1 + j] < a.cthr_raw) hit = i1 + j;
-            three = wave_min(hit);
-            if (three == INF) three = L;
-        }
-        const int touched = done ? i1 + w : L;
-        if (pbad < touched) {
-            if (lane == 0) report_error(errword, r, pbad, (int)(int8_t)q[pbad]);
-        }
-        if (HAS_SEQ) { // trim.cpp:86-98
-            int ni = INF, Ni = INF;
-            for (int j = lane; j < L; j += 64) {
-                const uint8_t c = sq[j];
-                if (c == 'n' && ni == INF) ni = j;
-                if (c == 'N' && Ni == INF) Ni = j;
-            }
-            ni = wave_min(ni);
-            Ni = wave_min(Ni);
-            if (ni != INF) three = ni - 1;
-            else if (Ni != INF) three = -2;
-        }
-        if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
-            five = -1;
-            three = -1;
-        }
-    }
-    return sk_cut_dev{five, three};
-}
-
-} // namespace
-
-template <int TEAM, bool HAS_SEQ>
-__global__ void __launch_bounds__(64)
-sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
-                    const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
-                    sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
-{
-    static_assert(TEAM == 16 || TEAM == 64, "teams of 16 or 64 lanes");
-    constexpr int RPW = 64 / TEAM; // reads per wave
-    constexpr bool SKIP = TEAM == 64; // whole-wave teams: prefix table + skip-ahead window search (see do_slot)
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x; // single-wave workgroups
-    const int g = lane / TEAM, tl = lane % TEAM;
-    // a read's buffer: rbuf bytes (the longest read the LDS path takes + what the lead stream may read
-    // past it), the teams' buffers 80 bytes apart on top so that their rows do not share banks
-    const uint32_t rbuf = a.team_rbuf, pitch = rbuf + 80u;
-    const uint32_t *row32 = reinterpret_cast<const uint32_t *>(lds + (uint32_t)g * pitch);
-    const uint8_t *rowb = lds + (uint32_t)g * pitch;
-    const uint64_t n_slots = (a.n_reads + RPW - 1) / RPW;
-    const uint64_t batch_end = a.n_reads ? rag_batch_end(offsets, lengths, a) : 0;
-    const uint32_t min4 = splat((uint32_t)a.qmin), max4 = splat((uint32_t)a.qmax);
-    const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));
-    const uint32_t cthr4 = splat((uint32_t)a.cthr);
-    const int range = a.qmax - a.qmin;
-
-    // known = the caller already holds this lane's read (start, length): the hand-over mode took them from the
-    // tile probe; otherwise they are loaded here
-    auto do_slot = [&](uint64_t slot, bool known, uint64_t o_known, int L_known) {
-        const uint64_t r = slot * RPW + g;
-        const bool valid = r < a.n_reads;
-        uint64_t o;
-        int L;
-        if (known) {
-            o = o_known;
-            L = valid ? L_known : 0;
-        } else {
-            const uint64_t rc = min(r, a.n_reads - 1);
-            uint64_t e;
-            if (offsets) {
-                o = offsets[rc];
-                e = offsets[rc + 1];
-            } else {
-                o = rc * a.stride;
-                e = o + (lengths ? lengths[rc] : a.read_len);
-            }
-            L = (valid && e >= o) ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
-        }
-        const bool big = L > (int)a.team_maxlen; // not through LDS
-        const bool scan = L > 0 && L >= a.lthr && !big; // trim.cpp:21
-
-        // ---- the reads of this wave into LDS, read after read, the whole wave copying: lane i of a
-        // piece fetches the 16 bytes at read offset 16*(c0 + i), wherever they are in the batch
-        auto stage = [&](const uint8_t *base) {
-#pragma unroll
-            for (int gg = 0; gg < RPW; ++gg) {
-                const int Lg = __builtin_amdgcn_readlane(scan ? L : 0, gg * TEAM);
-                if (Lg == 0) continue;
-                const uint64_t og = readlane_u64(o, gg * TEAM);
-                uint8_t *dst = lds + (uint32_t)gg * pitch;
-                const uint8_t *src = base + og;
-                const uint32_t nch = ((uint32_t)Lg + 15u) >> 4;
-                const bool all_inside = og + 16u * nch <= batch_end; // wave-uniform: no chunk of this read can leave the batch
-                for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
-                    const uint32_t so = 16u * (c0 + (uint32_t)lane);
-                    if (c0 + (uint32_t)lane < nch) {
-                        if (all_inside || og + so + 16u <= batch_end) {
-                            __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(dst + c0 * 16u), 16, 0, SK_DMA_AUX);
-                        } else { // the batch ends inside this chunk: byte by byte
-                            for (uint32_t j = 0; j < 16u && og + so + j < batch_end; ++j) dst[so + j] = src[so + j];
-                        }
-                    }
-                }
-            }
-            wait_vmcnt(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        stage(qual);
-
-        int five = -1, three = -1;
-        int w = L / 10; // trim.cpp:8
-        if (w == 0) w = L; // trim.cpp:30
-        const int nwin = scan ? L - w + 1 : 0;
-        const int T = a.craw * w;
-        // this lane's chunk of the read: c bytes, c/4 odd (conflict-free dword walks); SKIP: c/16 odd
-        // (conflict-free 16-byte walks)
-        const int c4 = !scan ? 1 : SKIP ? 4 * (((((L + TEAM - 1) / TEAM) + 15) >> 4) | 1) : ((((L + TEAM - 1) / TEAM + 3) >> 2) | 1);
-        const int c = 4 * c4;
-        const int s = tl * c;
-        const int sdw = s >> 2;
-
-        const bool has_win = scan && s < nwin;
-        const int we = min(s + c, nwin); // this lane's windows: [s, we)
-        uint32_t fa = NONE, fb = NONE, fc = NONE; // first >= T, first < T, first < T after fa (window indices)
-        bool bad = false;
-        if (SKIP) {
-            // ---- whole-wave teams (long reads): prefix sums + skip-ahead instead of walking every window.
-            // P16[k] = sum of the read's bytes before position 16k, so S_i = P(i + w) - P(i) for ANY i costs two
-            // table reads and two partial 16-byte sums; and since one step changes a window sum by at most 255,
-            // a lane at S_i - T = v < 0 can jump ceil(-v / 255) windows ahead without missing the first
-            // S >= T (and v / 255 + 1 ahead when looking for the first S < T).  Window sums of long reads sit
-            // far from the threshold almost everywhere (w * |Q - q|), so a lane evaluates a few dozen windows
-            // instead of its whole chunk: 6 instead of 48 VALU per dword of the read, exact for every input.
-            uint32_t *P16 = reinterpret_cast<uint32_t *>(lds + rbuf);
-            const sk_v4u *row128 = reinterpret_cast<const sk_v4u *>(rowb);
-            const int sg = s >> 4;
-            const int ngroups = scan ? max(0, min(c4 >> 2, (L - s + 15) >> 4)) : 0;
-            uint32_t sad = 0, run = 0;
-            for (int gi = 0; gi < ngroups; ++gi) { // 1. range check (trim.cpp:129) + local prefix of the chunk
-                const sk_v4u x = row128[sg + gi];
-                const int nval = L - (s + 16 * gi);
-                P16[sg + gi] = run;
-                if (nval >= 16) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        sad = __builtin_amdgcn_sad_u8(x[u], min4, sad);
-                        sad = __builtin_amdgcn_sad_u8(x[u], max4, sad);
-                        run = __builtin_amdgcn_sad_u8(x[u], 0u, run);
-                    }
-                } else { // the read ends inside this group
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t xq = first_bytes(x[u], nval - 4 * u, min4);
-                        sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
-                        sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
-                        run = __builtin_amdgcn_sad_u8(first_bytes(x[u], nval - 4 * u, 0u), 0u, run);
-                    }
-                }
-            }
-            bad = scan && sad != (uint32_t)(16 * ngroups * range); // fillers are legal chars
-            const uint32_t incl = team_scan_add<TEAM>(run, tl);
-            const uint32_t excl = incl - run;
-            for (int gi = 0; gi < ngroups; ++gi) atomicAdd(&P16[sg + gi], excl); // local -> global prefix (ds_add_u32)
-            // P(L) when L is a multiple of 16: one entry past the last group
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (tl == 0 && scan) P16[(L + 15) >> 4] = total;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            auto P = [&](int x) -> int { // sum of the bytes before position x, 0 <= x <= L
-                const int gi = x >> 4, r = x & 15;
-                uint32_t p = P16[gi];
-                const sk_v4u d = row128[gi];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) p = __builtin_amdgcn_sad_u8(first_bytes(d[u], r - 4 * u, 0u), 0u, p);
-                return (int)p;
-            };
-            auto SmT = [&](int i) -> int { return P(i + w) - P(i) - T; }; // sign bit <=> window average below the threshold
-            if (has_win) { // 2./3. trim.cpp:34-81: at most two searches per lane
-                int j = s, v = SmT(s);
-                if (v >= 0) {
-                    fa = (uint32_t)s;
-                    for (;;) { // the first window below the threshold after it
-                        j += v / 255 + 1;
-                        if (j >= we) break;
-                        v = SmT(j);
-                        if (v < 0) { fb = fc = (uint32_t)j; break; }
-                    }
-                } else {
-                    fb = (uint32_t)s;
-                    for (;;) { // the first window at or above the threshold
-                        j += (-v + 254) / 255;
-                        if (j >= we) break;
-                        v = SmT(j);
-                        if (v >= 0) { fa = (uint32_t)j; break; }
-                    }
-                    if (fa != NONE) {
-                        for (;;) { // and the first one below it again
-                            j += v / 255 + 1;
-                            if (j >= we) break;
-                            v = SmT(j);
-                            if (v < 0) { fc = (uint32_t)j; break; }
-                        }
-                    }
-                }
-            }
-        } else {
-        // ---- 1. range check + chunk sum (trim.cpp:129 and the prefix of 31-33)
-        uint32_t sad = 0, csum = 0;
-        {
-            // whole dwords of the chunk that lie inside the read need no masking: four loads in flight
-            const int inner = scan ? min(c4, max(0, (L - s) >> 2)) : 0;
-            int k = 0;
-            for (; k + 4 <= inner; k += 4) {
-                uint32_t x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = row32[sdw + k + u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    sad = __builtin_amdgcn_sad_u8(x[u], min4, sad);
-                    sad = __builtin_amdgcn_sad_u8(x[u], max4, sad);
-                    csum = __builtin_amdgcn_sad_u8(x[u], 0u, csum);
-                }
-            }
-            for (; k < c4; ++k) { // the rest of the chunk: the read may end inside it
-                uint32_t x = min4;
-                int nval = 0;
-                if (scan) {
-                    x = row32[sdw + k];
-                    nval = L - (s + 4 * k);
-                }
-                const uint32_t xq = first_bytes(x, nval, min4);
-                sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
-                sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
-                csum = __builtin_amdgcn_sad_u8(first_bytes(x, nval, 0u), 0u, csum);
-            }
-        }
-        // every dword visited contributes 4 * range when clean (fillers are legal chars)
-        bad = scan && sad != (uint32_t)(4 * c4 * range);
-        const uint32_t incl = team_scan_add<TEAM>(csum, tl);
-
-        // ---- 2. S_s - T for this lane's first window: P(s + w) - P(s) - T
-        const int dq = w / c, rem = w - dq * c;
-        const int kq = tl + dq; // the chunk position s + w lies in
-        const uint32_t below = (uint32_t)__shfl((int)incl, g * TEAM + min(max(kq - 1, 0), TEAM - 1), 64);
-        uint32_t part = 0;
-        {
-            const int remmax = __builtin_amdgcn_readfirstlane(wave_max(has_win ? rem : 0));
-            const int bdw = (kq * c) >> 2;
-            for (int j = 0; 4 * j < remmax; ++j)
-                if (has_win && 4 * j < rem) part = __builtin_amdgcn_sad_u8(first_bytes(row32[bdw + j], rem - 4 * j, 0u), 0u, part);
-        }
-        int v = (int)((kq >= 1 ? below : 0u) + part) - (int)(incl - csum) - T; // sign bit <=> window average below the threshold
-
-        // ---- 3. the lane's windows [s, we), 32 per trip: trim.cpp:34-81 without the breaks
-        {
-            const int mytrips = has_win ? (we - s + 31) >> 5 : 0;
-            const int tripmax = __builtin_amdgcn_readfirstlane(wave_max(mytrips));
-            const int ldw = (s + w) >> 2;
-            const uint32_t sh = (uint32_t)(w & 3); // s is a multiple of 4
-            uint32_t lead_lo = has_win ? row32[ldw] : 0u;
-            for (int tr = 0; tr < tripmax; ++tr) {
-                if (tr < mytrips) {
-                    uint32_t M = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int dwi = tr * 8 + k;
-                        const uint32_t y = row32[sdw + dwi];              // chars leaving the window
-                        const uint32_t lead_hi = row32[ldw + dwi + 1];
-                        const uint32_t x = __builtin_amdgcn_alignbyte(lead_hi, lead_lo, sh); // chars entering
-                        lead_lo = lead_hi;
-                        const int d = (int)(((x | H4) - y) ^ H4); // per byte: x - y as int8 (both < 128)
-                        const int t1 = __builtin_amdgcn_sdot4(d, 0x00000001, v, false);
-                        const int t2 = __builtin_amdgcn_sdot4(d, 0x00000101, v, false);
-                        const int t3 = __builtin_amdgcn_sdot4(d, 0x00010101, v, false);
-                        const int t4 = __builtin_amdgcn_sdot4(d, 0x01010101, v, false);
-                        M = __builtin_amdgcn_alignbit(M, (uint32_t)v, 31);
-                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
-                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
-                        M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
-                        v = t4;
-                    }
-                    // bit (31 - j) of M: window base + j is below the threshold
-                    const int base = s + 32 * tr;
-                    const int nv = we - base;
-                    const uint32_t vmask = nv >= 32 ? ~0u : ~(~0u >> nv); // nv >= 1 here
-                    const uint32_t lt = M & vmask, ge = ~M & vmask;
-                    fa = min(fa, __builtin_elementwise_add_sat(ffbh_or_none(ge), (uint32_t)base));
-                    fb = min(fb, __builtin_elementwise_add_sat(ffbh_or_none(lt), (uint32_t)base));
-                    // windows of this trip strictly after fa: the low (base + 31 - fa) bits
-                    const uint32_t width = __builtin_elementwise_sub_sat((uint32_t)(base + 31), fa);
-                    const uint32_t low = (1u << (width & 31u)) - 1u;
-                    const uint32_t after = lt & (width >= 32u ? ~0u : low);
-                    fc = min(fc, __builtin_elementwise_add_sat(ffbh_or_none(after), (uint32_t)base));
-                }
-            }
-        }
-
-        }
-
-        // ---- 4. the team's windows: trim.cpp:42 and :61
-        const int fai = fa == NONE ? INF : (int)fa, fbi = fb == NONE ? INF : (int)fb, fci = fc == NONE ? INF : (int)fc;
-        const int i0 = a.no5 ? INF : team_min<TEAM>(fai);
-        const bool have5 = !a.no5 && i0 != INF;
-        const bool found5 = a.no5 || i0 != INF;
-        int cand = INF;
-        if (a.no5) cand = fbi;
-        else if (i0 != INF && has_win) cand = (s > i0) ? fbi : (fai == i0 ? fci : INF);
-        const int i1 = team_min<TEAM>(cand);
-        const bool done = found5 && i1 != INF;
-
-        five = 0;
-        three = L;
-        if (have5) { // trim.cpp:46-51: the first char >= threshold at or after i0 (one exists inside the window)
-            int hit = INF;
-            const int d0 = i0 >> 2, ndw = ((i0 & 3) + w + 3) >> 2;
-            for (int d = tl; d < ndw && hit == INF; d += TEAM) {
-                uint32_t f = ge_flags(row32[d0 + d], cthr4);
-                if (d == 0) f &= ~0u << (8 * (i0 & 3));
-                if (f) hit = 4 * (d0 + d) + (__builtin_ctz(f) >> 3);
-            }
-            hit = team_min<TEAM>(hit);
-            five = hit == INF ? 0 : hit;
-        }
-        if (done) { // trim.cpp:65-70
-            int hit = INF;
-            const int d0 = i1 >> 2, ndw = ((i1 & 3) + w + 3) >> 2;
-            for (int d = tl; d < ndw && hit == INF; d += TEAM) {
-                uint32_t f = ge_flags(row32[d0 + d], cthr4) ^ H4;
-                if (d == 0) f &= ~0u << (8 * (i1 & 3));
-                if (f) hit = 4 * (d0 + d) + (__builtin_ctz(f) >> 3);
-            }
-            hit = team_min<TEAM>(hit);
-            three = hit == INF ? L : hit;
-        }
-
-        // ---- range error: only if the first bad char is one the reference would have read
-        if (__builtin_amdgcn_ballot_w64(bad)) {
-            int pb = INF;
-            if (bad) {
-                for (int k = 0; k < c4 && s + 4 * k < L && pb == INF; ++k) {
-                    const uint32_t f = keep_first(bad_flags(row32[sdw + k], min4, hi4), L - (s + 4 * k));
-                    if (f) pb = s + 4 * k + (__builtin_ctz(f) >> 3);
-                }
-            }
-            pb = team_min<TEAM>(pb);
-            const int touched = done ? i1 + w : L;
-            if (scan && pb < touched && tl == 0) report_error(errword, r, pb, (int)(int8_t)rowb[pb]);
-        }
-
-        // ---- the N rule: trim.cpp:86-98, the sequences through the same buffers
-        if (HAS_SEQ) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stage(seq);
-            uint32_t nlo = NONE, anyN = 0; // bit index of the first lowercase n; any uppercase N
-            const int c4m = __builtin_amdgcn_readfirstlane(wave_max(scan ? c4 : 0));
-            for (int k = 0; k < c4m; ++k) {
-                if (scan && k < c4 && s + 4 * k < L) {
-                    const uint32_t x = first_bytes(row32[sdw + k], L - (s + 4 * k), 0u);
-                    const uint32_t y = (x | 0x20202020u) ^ 0x6e6e6e6eu;
-                    const uint32_t either = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & H4;
-                    const uint32_t lower = either & (x << 2); // bit 5 of the byte moved onto its flag
-                    nlo = min(nlo, __builtin_elementwise_add_sat(ffbl_or_none(lower), (uint32_t)(8 * (s + 4 * k))));
-                    anyN |= either ^ lower;
-                }
-            }
-            const int nl = team_min<TEAM>(nlo == NONE ? INF : (int)(nlo >> 3));
-            anyN = team_or<TEAM>(anyN);
-            if (nl != INF) three = nl - 1;
-            else if (anyN) three = -2;
-        }
-        if (!scan || !found5 || (three - five < a.lthr)) { // trim.cpp:103-108
-            five = -1;
-            three = -1;
-        }
-        if (valid && !big && tl == 0) out[r] = sk_cut_dev{five, three};
-        // every LDS read of this slot is done before the next slot's DMA may overwrite the buffers
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-        // ---- reads too long for the LDS buffer: the whole wave, one after the other, from global memory
-        if (__builtin_amdgcn_ballot_w64(big)) {
-#pragma unroll
-            for (int gg = 0; gg < RPW; ++gg) {
-                if (!__builtin_amdgcn_readlane((int)big, gg * TEAM)) continue;
-                const int Lg = __builtin_amdgcn_readlane(L, gg * TEAM);
-                const uint64_t og = readlane_u64(o, gg * TEAM);
-                const uint64_t rg = slot * RPW + gg;
-                const sk_cut_dev cut = scan_read_global<HAS_SEQ>(qual + og, HAS_SEQ ? seq + og : nullptr, Lg, rg, lane, a, errword);
-                if (lane == 0) out[rg] = cut;
-            }
-        }
-    };
-
-    if (a.buf_bytes) {
-        // only the 64-read tiles sk_scan_tile_any_kernel left (the same test as there) -- if it left any:
-        // it has put this scan's number into the word after the error word for every tile it skipped
-        if (*reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
-        // Runs of 8 consecutive reads are dealt to the waves (so that the reads of one left-over tile spread
-        // over the device).  A wave asks the question for the tile its run lies in; the probe leaves read
-        // 64*tile + l's start and length in lane l, so the run's reads need no further offset loads.
-        // (A ticket counter in global memory instead of the fixed deal, one atomic per read, measured slower:
-        // 0.82 against 0.69 ms on 64 200 reads of 1-30 kb.)
-        constexpr uint64_t RUN = 8;
-        const uint64_t n_runs = (a.n_reads + RUN - 1) / RUN;
-        for (uint64_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
-            const sk_rag_tile pr = rag_probe((run * RUN) >> 6, lane, offsets, lengths, a);
-            if (rag_tile_fits(pr, a.buf_bytes)) continue;
-            for (uint64_t slot = run * RUN / RPW; slot < (run + 1) * RUN / RPW && slot < n_slots; ++slot) {
-                const int idx = (int)((slot * RPW + (uint64_t)g) & 63u); // this lane's read within the tile
-                const uint32_t ro = (uint32_t)__shfl((int)pr.rowoff, idx, 64);
-                const int len = __shfl(pr.len, idx, 64);
-                do_slot(slot, true, pr.start + ro, len);
-            }
-        }
-    } else {
-        for (uint64_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) do_slot(slot, false, 0, 0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------
 namespace {
-
-// The dynamic-LDS ceiling of a kernel is a property of (device, function) in the HIP runtime; it is
-// raised ONCE per pair to the CU's 160 KiB and every launch then passes its own size.  (Setting it per
-// launch to that launch's size raced between host threads scanning batches of different strides on one
-// device: A sets 80 KiB, B sets 10 KiB, A's launch fails.)  Also caches the kernel's register count.
-struct kernel_facts {
-    hipError_t status = hipSuccess;
-    int regs = 0;
-};
-template <typename K>
-kernel_facts prepare_kernel(K kern)
-{
-    static std::mutex mu;
-    static std::map<std::pair<int, const void *>, kernel_facts> seen;
-    int device = 0;
-    (void)hipGetDevice(&device);
-    const void *fn = reinterpret_cast<const void *>(kern);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = seen.find({device, fn});
-    if (it != seen.end()) return it->second;
-    kernel_facts f;
-    f.status = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_PER_CU);
-    hipFuncAttributes fa;
-    if (f.status == hipSuccess && hipFuncGetAttributes(&fa, fn) == hipSuccess) f.regs = fa.numRegs;
-    if (f.status == hipSuccess) seen[{device, fn}] = f; // a failure is retried by the next launch
-    return f;
-}
 
 int tile_nbuf_default()
 {
@@ -1791,114 +942,4 @@ extern "C" hipError_t sk_launch_tile_ablate(int mode, const uint8_t *qual, sk_cu
     default: return hipErrorInvalidValue;
     }
 #undef SK_GO
-}
-
-extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
-                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
-                                     const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
-{
-    // max_len = the longest read the caller expects (0 = unknown).  Teams of 16 lanes (4 reads per
-    // wave) up to 2 KiB, the whole wave beyond; reads longer than the buffer sized here still come out
-    // right, from global memory (scan_read_global).
-    if (a->n_reads == 0) return hipSuccess;
-    if (max_len == 0) max_len = 32768;
-    static const uint64_t team16_max = [] { const char *e = getenv("SK_TEAM16_MAX"); return e ? (uint64_t)atoll(e) : 4096ull; }();
-    const int team = max_len <= team16_max ? 16 : 64;
-    const int rpw = 64 / team;
-    uint64_t cap = max_len;
-    const uint64_t cap_max = (uint64_t)(SK_LDS_PER_CU / 2) / rpw - 1024; // at least two waves per CU
-    if (cap > cap_max) cap = cap_max;
-    sk_scan_args at = *a;
-    at.team_maxlen = (uint32_t)cap;
-    // what the lead stream and the 32-window trips may read past the read: a chunk + 32 windows + slack
-    at.team_rbuf = (uint32_t)((cap + cap / team + 4 + 32 + SK_TILE_SLACK + 15) & ~(uint64_t)15);
-    // whole-wave teams keep a prefix table beside the read: 4 bytes per 16 (sk_scan_team_kernel, SKIP)
-    const uint32_t lds_bytes = (uint32_t)rpw * (at.team_rbuf + 80u) + (team == 64 ? (at.team_rbuf >> 2) + 64u : 0u);
-    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    static const int wave_cap = [] { const char *e = getenv("SK_TEAM_WAVES"); return e ? atoi(e) : 16; }();
-    if (per_cu > wave_cap) per_cu = wave_cap;
-    if (per_cu < 1) return hipErrorInvalidValue;
-    const uint64_t n_slots = (a->n_reads + rpw - 1) / rpw;
-    uint64_t grid = (uint64_t)cu_count * per_cu;
-    if (grid > n_slots) grid = n_slots;
-    if (grid == 0) return hipSuccess;
-    auto launch = [&](auto kern) {
-        const kernel_facts facts = prepare_kernel(kern);
-        if (facts.status != hipSuccess) return facts.status;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
-                           errword, at);
-        return hipGetLastError();
-    };
-    if (team == 16) return a->truncn ? launch(sk_scan_team_kernel<16, true>) : launch(sk_scan_team_kernel<16, false>);
-    return a->truncn ? launch(sk_scan_team_kernel<64, true>) : launch(sk_scan_team_kernel<64, false>);
-}
-
-// ------------------------------------------------------------------------------------------
-// measurement aid: what a read-only stream of this buffer gets on this device (sk_probe_read_bandwidth)
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sk_read_probe_kernel(const sk_v4u *__restrict__ src, size_t n16, uint32_t *sink)
-{
-    constexpr int UNROLL = 4;
-    size_t i = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * 256 * UNROLL;
-    sk_v4u acc = {0, 0, 0, 0};
-    for (; i + 256 * (UNROLL - 1) < n16; i += step) {
-        sk_v4u v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + 256 * u);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
-    }
-    // keeps the loads alive; quality bytes never fold to this value
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && n16 == 1) sink[threadIdx.x & 1] = 1;
-}
-
-extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_read_probe(const void *buf, size_t bytes, uint32_t *sink, int cu_count,
-                                           hipStream_t stream)
-{
-    hipLaunchKernelGGL(sk_read_probe_kernel, dim3((unsigned)cu_count * 32u), dim3(256), 0, stream,
-                       reinterpret_cast<const sk_v4u *>(buf), bytes / 16, sink);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// pair classification: reference src/trim_paired.cpp:543-567 over the cuts of a scan (mates at 2k, 2k+1).
-// One 16-byte load per pair and lane; the four class counts of a wave come from ballots, one lane adds them.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sk_pair_count_kernel(const sk_v4i *__restrict__ cuts, uint64_t n_pairs, uint8_t *__restrict__ classes,
-                                                            unsigned long long *counters)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    unsigned long long c_both = 0, c_first = 0, c_second = 0, c_none = 0; // per wave, kept by every lane
-    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_pairs; k0 += stride) {
-        const uint64_t k = k0 + threadIdx.x;
-        int cls = -1;
-        if (k < n_pairs) {
-            const sk_v4i c = __builtin_nontemporal_load(cuts + k); // {five1, three1, five2, three2}
-            const bool r1 = c[1] >= 0, r2 = c[3] >= 0;             // src/trim_paired.cpp:500,502
-            cls = r1 ? (r2 ? 0 : 1) : (r2 ? 2 : 3);
-            if (classes) classes[k] = (uint8_t)cls;
-        }
-        c_both += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 0));
-        c_first += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 1));
-        c_second += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 2));
-        c_none += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cls == 3));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (c_both) atomicAdd(counters + 0, c_both);
-        if (c_first) atomicAdd(counters + 1, c_first);
-        if (c_second) atomicAdd(counters + 2, c_second);
-        if (c_none) atomicAdd(counters + 3, c_none);
-    }
-}
-
-extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_pair_count(const sk_cut_dev *cuts, uint64_t n_pairs, uint8_t *classes,
-                                           unsigned long long *counters, int cu_count, hipStream_t stream)
-{
-    if (n_pairs == 0) return hipSuccess;
-    uint64_t grid = (n_pairs + 255) / 256;
-    if (grid > (uint64_t)cu_count * 16) grid = (uint64_t)cu_count * 16;
-    hipLaunchKernelGGL(sk_pair_count_kernel, dim3((unsigned)grid), dim3(256), 0, stream, reinterpret_cast<const sk_v4i *>(cuts), n_pairs,
-                       classes, counters);
-    return hipGetLastError();
 }
