@@ -535,3 +535,48 @@ def test_long_reads_hovering_at_the_threshold(sk_ctx):
         want, _ = ob.oracle_trim_batch(po, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
         got = sk_ctx.trim_batch(p, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
         assert (got == want).all(), L
+
+
+def test_random_fuzz_medium_and_long_reads(sk_ctx):
+    """Random batches for the general kernel (teams of 16, whole-wave teams with the skip-ahead search, the
+    in-kernel global-memory fallback): lengths 330 .. 20 000 log-uniform with a few beyond the LDS buffer, every
+    encoding, thresholds from 0 to beyond the scale, -x, -n, -l up to beyond the read; ragged and stride + lengths."""
+    rng = np.random.default_rng(2027)
+    for trial in range(24):
+        qt = ["sanger", "solexa", "illumina"][trial % 3]
+        lo, hi = {"sanger": (33, 74), "solexa": (59, 105), "illumina": (64, 105)}[qt]
+        n = 150
+        lens = np.exp(rng.uniform(np.log(330), np.log(20_000), size=n)).astype(np.uint32)
+        if trial % 6 == 0:
+            lens[:3] = [90_000, 120_000, 100_001]  # beyond any LDS buffer: the byte-by-byte fallback
+        if trial % 4 == 1:
+            lens[:] = lens[0]  # one length: the all-reads mode via a fixed stride below
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        tot = int(offs[-1])
+        mid = rng.integers(lo + 8, hi - 8)
+        mode = trial % 4
+        if mode == 0:
+            qual = np.clip(rng.normal(mid, 7, tot).astype(int), lo, hi)
+        elif mode == 1:
+            qual = np.clip(mid + rng.integers(-2, 3, size=tot), lo, hi)
+        elif mode == 2:  # long plateaus: every few thousand bases the level changes
+            level = np.repeat(rng.integers(lo, hi, size=tot // 1500 + 2), 1500)[:tot]
+            qual = np.clip(level + rng.integers(-3, 4, size=tot), lo, hi)
+        else:
+            qual = np.where(rng.random(tot) < 0.5, lo, hi)
+        qual = qual.astype(np.uint8)
+        seq = rng.choice(np.frombuffer(b"ACGT" * 300 + b"Nn", dtype=np.uint8), size=tot)
+        q = int(rng.choice([0, 2, 15, 20, 25, 30, 41, 60]))
+        l = int(rng.choice([0, 20, 300, 5000, 30_000]))
+        x, tn = trial % 2, (trial // 2) % 2
+        p, po = both_params(qt, q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=4)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offs)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, ("ragged", trial, qt, q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+        if trial % 4 == 1:  # the same reads as a uniform fixed-stride batch
+            L = int(lens[0])
+            got = sk_ctx.trim_batch(p, qual, seq, stride=L, read_len=L, n_reads=n)
+            assert (got == want).all(), ("uniform", trial, L)
