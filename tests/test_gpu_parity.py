@@ -580,3 +580,41 @@ def test_random_fuzz_medium_and_long_reads(sk_ctx):
             L = int(lens[0])
             got = sk_ctx.trim_batch(p, qual, seq, stride=L, read_len=L, n_reads=n)
             assert (got == want).all(), ("uniform", trial, L)
+
+
+def test_segmented_long_rows_and_partial_tiles(sk_ctx):
+    """Segmented batches without -n, rows up to 312 bytes (8 waves per CU), length groups of every size (1 read ...
+    several full tiles + a partial one) so that full and partial tiles alternate in every order; cuts in read order
+    and in slot order; a planted range error.  (Written for a variant that staged the next tile in registers -- 20
+    KiB through 80 VGPRs at two waves per SIMD; it measured 11 % slower than LDS-DMA, 3.8 against 4.2 TB/s: the
+    80 ds_write_b128 per tile cost more than the prefetch gains -- and kept for its coverage.)"""
+    from fastq_util import segment_by_length
+    rng = np.random.default_rng(99)
+    lens = np.concatenate([rng.integers(230, 302, size=60_000), rng.integers(75, 302, size=40_000),
+                           np.full(64 * 7, 250), np.full(1, 301), np.full(65, 77)]).astype(np.uint32)
+    rng.shuffle(lens)
+    n = len(lens)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    tot = int(offsets[-1])
+    qual = np.clip(rng.normal(58, 9, tot).astype(int), 33, 74).astype(np.uint8)
+    drop = rng.random(tot) < 0.0004
+    qual[np.nonzero(drop)[0]] = 34
+    seq = np.full(tot, 65, dtype=np.uint8)
+    ss, qs, tiles, out_index, max_stride = segment_by_length(seq, qual, offsets)
+    assert max_stride == 312
+    for q, l, x in ((20, 20, 0), (24, 100, 1)):
+        p, po = both_params("sanger", q, l, x, 0)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offsets, threads=8)
+        assert err is None
+        got = sk_ctx.trim_segmented(p, qs, tiles, out_index, max_stride)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (q, l, x, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+        got = sk_ctx.trim_segmented(p, qs, tiles, out_index, max_stride, slot_order=True)
+        assert (got == want[out_index]).all()
+    q2 = qual.copy()
+    q2[int(offsets[77_777]) + 9] = 12
+    _, qs2, tiles2, oi2, ms2 = segment_by_length(seq, q2, offsets)
+    with pytest.raises(capi.RangeError) as ei:
+        sk_ctx.trim_segmented(capi.make_params("sanger", 20, 0), qs2, tiles2, oi2, ms2)
+    assert (ei.value.read, ei.value.pos, ei.value.ch) == (77_777, 9, 12)
