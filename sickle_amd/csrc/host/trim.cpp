@@ -269,6 +269,29 @@ int Abstract_Trimmer::open_device()
     ctxs.assign(device_ids.size(), nullptr);
     slots.assign((size_t)n_slots(), Slot());
     device_opener = std::thread([this] {
+        // Pinned staging sized for a whole ingest batch, allocated during start-up so that hipHostMalloc
+        // (0.08 s per 0.4 GB) also hides behind the first reads.  A batch holds at most ~batch_len
+        // bytes of text per input file; quality is under half of it.  Too small only means a
+        // later grow().  With one device the pinning runs on a thread of its own, beside the creation of
+        // the context (the first hipStreamCreate takes 0.16 s): tools/probes/hip_init_parallel.py -- both are
+        // done after 0.27 s instead of 0.32 s.
+        const size_t text = (size_t)batch_len * (size_t)staging_files;
+        auto pin_all = [this, text](bool with_ctx) {
+            for (size_t i = 0; i < slots.size(); ++i) {
+                {   // a published slot belongs to the main thread from then on
+                    std::lock_guard<std::mutex> lk(open_lock);
+                    if (slots_ready > (int)i) continue;
+                }
+                // without a context a failure is not fatal here: the pass with the context repeats the slot and
+                // reports (no device at all must end in sk_create's message, not in this one)
+                if (!grow(with_ctx ? ctx_of((int)i) : nullptr, slots[i], text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0)) return;
+                std::lock_guard<std::mutex> lk(open_lock);
+                if (slots_ready < (int)i + 1) slots_ready = (int)i + 1;
+                open_cv.notify_all();
+            }
+        };
+        std::thread pinner;
+        if (device_ids.size() == 1) pinner = std::thread(pin_all, false);
         for (size_t g = 0; g < device_ids.size(); ++g) {
             const int rc = sk_create(device_ids[g], kSlots, &ctxs[g]);
             if (rc != SK_OK) {
@@ -276,23 +299,20 @@ int Abstract_Trimmer::open_device()
                 fprintf(stderr, "****Error: no usable MI355X (gfx950) device %d for the quality scan (sk_create: %d).\n\n",
                         device_ids[g], rc);
                 ctxs[g] = nullptr;
+                if (pinner.joinable()) pinner.join();
                 std::lock_guard<std::mutex> lk(open_lock);
                 open_failed = open_done = true;
                 open_cv.notify_all();
                 return;
             }
         }
-        // Pinned staging sized for a whole ingest batch, allocated here so that hipHostMalloc
-        // (slow, ~1 GB/s) also hides behind the first reads.  A batch holds at most ~batch_len
-        // bytes of text per input file; quality is under half of it.  Too small only means a
-        // later grow().
-        const size_t text = (size_t)batch_len * (size_t)staging_files;
-        for (size_t i = 0; i < slots.size(); ++i) {
-            grow(ctx_of((int)i), slots[i], text / 2 + (text >> 4), text / 96 + 1024, trunc_n != 0);
+        {
             std::lock_guard<std::mutex> lk(open_lock);
-            slots_ready = (int)i + 1;
+            ctx_ready = true;
             open_cv.notify_all();
         }
+        if (pinner.joinable()) pinner.join();
+        pin_all(true); // nothing to do for the slots the pinner finished
         std::lock_guard<std::mutex> lk(open_lock);
         devices_ok = open_done = true;
         open_cv.notify_all();
@@ -309,7 +329,7 @@ void Abstract_Trimmer::ensure_device()
 void Abstract_Trimmer::ensure_slot(int slot)
 {
     std::unique_lock<std::mutex> lk(open_lock);
-    open_cv.wait(lk, [&] { return open_done || slots_ready > slot; });
+    open_cv.wait(lk, [&] { return open_done || (ctx_ready && slots_ready > slot); });
     if (open_failed) fatal_exit(EXIT_FAILURE); // the opener has printed why
 }
 
@@ -336,22 +356,28 @@ void Abstract_Trimmer::close_device()
     devices_ok = false;
 }
 
-void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq)
+bool Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq)
 {
+    // ctx == nullptr: start-up, the context is still being created on another thread -- the context-free
+    // pinned allocator of the library (the same hipHostMalloc / hipHostFree underneath)
     auto fail = [&](const char *what) {
+        if (!ctx) return false;
         fprintf(stderr, "****Error: could not allocate pinned %s buffer: %s\n\n", what, sk_last_error(ctx));
         fatal_exit(EXIT_FAILURE);
+        return false;
     };
+    auto sk_host_alloc = [](sk_ctx *c, size_t bytes) -> void * { return c ? ::sk_host_alloc(c, bytes) : sk_bgzf_host_alloc(bytes); };
+    auto sk_host_free = [](sk_ctx *c, void *p) { if (c) ::sk_host_free(c, p); else sk_bgzf_host_free(p); };
     if (bytes + 64 > s.cap_bytes || (need_seq && !s.seq)) {
         const size_t cap = std::max(s.cap_bytes, bytes + 64 + (bytes >> 3));
         sk_host_free(ctx, s.qual);
         sk_host_free(ctx, s.seq);
         s.seq = nullptr;
         s.qual = (uint8_t *)sk_host_alloc(ctx, cap);
-        if (!s.qual) fail("quality");
+        if (!s.qual) return fail("quality");
         if (need_seq) {
             s.seq = (uint8_t *)sk_host_alloc(ctx, cap);
-            if (!s.seq) fail("sequence");
+            if (!s.seq) return fail("sequence");
         }
         s.cap_bytes = cap;
     }
@@ -361,9 +387,10 @@ void Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bo
         sk_host_free(ctx, s.cuts);
         s.offsets = (uint64_t *)sk_host_alloc(ctx, cap * sizeof(uint64_t));
         s.cuts = (sk_cut *)sk_host_alloc(ctx, cap * sizeof(sk_cut));
-        if (!s.offsets || !s.cuts) fail("index");
+        if (!s.offsets || !s.cuts) return fail("index");
         s.cap_reads = cap;
     }
+    return true;
 }
 
 void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)

@@ -217,12 +217,13 @@ private:
     std::mutex open_lock;
     std::condition_variable open_cv;
     int slots_ready = 0;      // slots [0, slots_ready) have their pinned staging
+    bool ctx_ready = false;   // every sk_ctx exists
     bool open_failed = false, open_done = false;
     void ensure_device();     // everything the opener does
     void ensure_slot(int slot);
     std::vector<Slot> slots;     // n_slots(): slot s belongs to ctxs[s % G]
     sk_ctx *ctx_of(int slot) { return ctxs[(size_t)slot % ctxs.size()]; }
-    void grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq);
+    bool grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bool need_seq); // false: only without a context
 };
 
 #include "WorkerPool.h"
