@@ -48,10 +48,24 @@ public:
     const T &operator[](size_t i) const { return p[i]; }
     const T *begin() const { return p; }
     const T *end() const { return p + n; }
+    const T *data() const { return p; }
 
 private:
     T *p = nullptr;
     size_t n = 0;
+};
+
+// a read-only view of consecutive elements (a whole RawVec or a part of one); the owner outlives it
+template <typename T> struct Span {
+    const T *p = nullptr;
+    size_t n = 0;
+    Span() = default;
+    Span(const T *first, size_t count) : p(first), n(count) {}
+    Span(const RawVec<T> &v) : p(v.data()), n(v.size()) {}
+    size_t size() const { return n; }
+    const T &operator[](size_t i) const { return p[i]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
 };
 
 #endif

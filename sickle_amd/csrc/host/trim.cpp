@@ -393,7 +393,14 @@ bool Abstract_Trimmer::grow(sk_ctx *ctx, Slot &s, size_t bytes, size_t reads, bo
     return true;
 }
 
-void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
+size_t Abstract_Trimmer::piece_reads() const
+{
+    static const size_t forced = [] { const char *e = getenv("SICKLE_SUBBATCH_READS"); return e ? (size_t)atoll(e) : (size_t)0; }();
+    if (threads != 1) return (size_t)-1;
+    return forced ? forced : (size_t)600000;
+}
+
+void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
 {
     ensure_slot(slot);
     Slot &s = slots[(size_t)slot];
@@ -536,7 +543,7 @@ void Abstract_Trimmer::submit_scan(int slot, const RawVec<FQEntry> &reads)
     }
 }
 
-const cutsites *Abstract_Trimmer::wait_scan(int slot, const RawVec<FQEntry> &reads)
+const cutsites *Abstract_Trimmer::wait_scan(int slot, Span<FQEntry> reads)
 {
     static_assert(sizeof(cutsites) == sizeof(sk_cut), "cutsites must match the C ABI's sk_cut");
     sk_err e;

@@ -155,10 +155,17 @@ protected:
     void close_device();
     // packs the quality (and, with -n, sequence) bytes of `reads` into the slot's pinned buffers
     // and enqueues H2D + scan + D2H; returns at once
-    void submit_scan(int slot, const RawVec<FQEntry> &reads);
+    void submit_scan(int slot, Span<FQEntry> reads);
     // blocks until the slot is done; on an out-of-range quality prints the reference's message
     // (src/trim.cpp:130-135) and exits 1.  The cut array stays valid until the slot is reused.
-    const cutsites *wait_scan(int slot, const RawVec<FQEntry> &reads);
+    const cutsites *wait_scan(int slot, Span<FQEntry> reads);
+
+    // At -a 1 the file order is the input order whatever the batches are, so an ingest batch (up to 256 MiB of
+    // text per file) may go through the device and the output stages in several pieces: the first piece is
+    // written while the rest is still being packed, and the last one leaves a short tail.  With -a T > 1 the
+    // queue-major order is per ingest batch (src/trim_paired.cpp:388-403) and a batch stays whole.
+    // -> number of records per piece (SICKLE_SUBBATCH_READS overrides: tests force tiny pieces)
+    size_t piece_reads() const;
 
     // Frames records [0, n) of a batch on all host threads: record i is made from the four lines
     // starting at line first_line(i) with position position(i).  If any record is malformed the

@@ -313,8 +313,11 @@ Trim_Paired::Assembled *Trim_Paired::output_paired(Work &w)
     discard_s1 += b_discard_s1;
     discard_s2 += b_discard_s2;
     // src/trim_paired.cpp:593 computes `total` from the PER-BATCH locals that shadow the members,
-    // so the summary's "Total input FastQ records" is the size of the last batch written.
-    total = b_kept_p + b_kept_s1 + b_kept_s2 + b_discard_p + b_discard_s1 + b_discard_s2;
+    // so the summary's "Total input FastQ records" is the size of the last INGEST batch written
+    // (a batch may arrive here in pieces at -a 1)
+    if (w.first_of_batch) batch_total = 0;
+    batch_total += b_kept_p + b_kept_s1 + b_kept_s2 + b_discard_p + b_discard_s1 + b_discard_s2;
+    total = batch_total;
 
     Assembled *a = new Assembled();
     for (Part &o : part_out) {
@@ -322,9 +325,7 @@ Trim_Paired::Assembled *Trim_Paired::output_paired(Work &w)
         a->fq2.push_back(std::move(o.fq2));
         a->singles.push_back(std::move(o.singles));
     }
-    delete w.batch;
-    delete w.batch2;
-    w.batch = w.batch2 = nullptr;
+    w.frame.reset(); // the last piece of a batch releases its text and its record array
     return a;
 }
 
@@ -381,9 +382,9 @@ int Trim_Paired::trim_main()
             }
             rd.stop();
             StageClock::Scope fr(clk_frame);
-            Work *w = new Work();
-            w->batch = batch;
-            w->batch2 = batch2;
+            std::shared_ptr<Frame> frame = std::make_shared<Frame>();
+            frame->batch = batch;
+            frame->batch2 = batch2;
             // :350-404 -- pairs are framed until the batch ends or until the running sum of mate-1
             // lengths passes batch_len (the check sits BEFORE each pair, :352-358); what is left
             // of the batch after that is dropped
@@ -401,16 +402,16 @@ int Trim_Paired::trim_main()
                 error("Reading interleaved pair: read1 loaded, but no read2 to load. Maybe it's not an interleaved file?");
                 fatal_exit(EXIT_FAILURE);
             }
-            w->reads.resize(2 * pairs);
+            frame->all.resize(2 * pairs);
             // record positions restart at 1 in every batch in PE (:309-310)
             if (input_inter) {
-                frame_records(w->reads, *batch, 2 * pairs, [](size_t i) { return 4 * i; },
+                frame_records(frame->all, *batch, 2 * pairs, [](size_t i) { return 4 * i; },
                               [](size_t i) { return (int)i + 1; });
             } else {
                 // mate 1 first, then mate 2: a malformed mate 1 anywhere is reported before any
                 // mate 2 problem only if it comes first in the reference's own order, which
                 // alternates -- so check the pairs in that order afterwards
-                RawVec<FQEntry> &rd = w->reads;
+                RawVec<FQEntry> &rd = frame->all;
                 WorkerPool &pool = WorkerPool::instance();
                 const size_t parts = (size_t)pool.size() * 4;
                 std::vector<size_t> first_bad(parts, (size_t)-1);
@@ -429,15 +430,19 @@ int Trim_Paired::trim_main()
                         break;
                     }
             }
-            if (chars_read_from_batch == 0) { // :407-409
-                delete batch;
-                delete batch2;
-                delete w;
-                break;
-            }
+            if (chars_read_from_batch == 0) break; // :407-409 (the frame goes with its text)
             fr.stop();
             StageClock::mark("batch framed");
-            parsed.push(w);
+            // whole, or at -a 1 in pieces of whole pairs (trim.h: piece_reads)
+            const size_t step = std::max<size_t>(1, piece_reads() / 2);
+            for (size_t lo = 0; lo < pairs; lo += std::min(step, pairs - lo)) {
+                const size_t hi = lo + std::min(step, pairs - lo);
+                Work *w = new Work();
+                w->frame = frame;
+                w->reads = Span<FQEntry>(frame->all.data() + 2 * lo, 2 * (hi - lo));
+                w->first_of_batch = lo == 0;
+                parsed.push(w);
+            }
         }
         parsed.close();
         // the run may end before the files do (different batch lengths, :335-338): drain the

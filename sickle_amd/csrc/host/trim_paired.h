@@ -14,11 +14,24 @@ public:
     int recommended_batch_len(const char *path, int max_batch_len);
 
 protected:
-    struct Work {
+    // one ingest batch, framed: owns the text (views of the mapped input) and the record array
+    struct Frame {
         Batch *batch = nullptr, *batch2 = nullptr;
-        RawVec<FQEntry> reads; // mate 1 of pair k at 2k, mate 2 at 2k+1 (the reference's scan order)
-        std::vector<cutsites> cuts;
+        RawVec<FQEntry> all; // mate 1 of pair k at 2k, mate 2 at 2k+1 (the reference's scan order)
+        ~Frame()
+        {
+            delete batch;
+            delete batch2;
+        }
     };
+    // what travels through the device and output stages: a whole frame, or at -a 1 a piece of one
+    struct Work {
+        std::shared_ptr<Frame> frame;
+        Span<FQEntry> reads;
+        std::vector<cutsites> cuts;
+        bool first_of_batch = true;
+    };
+    int batch_total = 0; // records of the ingest batch being written (for the summary's "Total", see output_paired)
     int init_streams();
     void close_streams();
     // the text of one batch for the three outputs, in pieces (one per host thread), in order

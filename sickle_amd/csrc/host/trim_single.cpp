@@ -221,8 +221,7 @@ std::vector<std::string> *Trim_Single::output_single(Work &w)
         discard += part_discard[part];
     }
     total = kept + discard;
-    delete w.batch;
-    w.batch = nullptr;
+    w.frame.reset();
     return new std::vector<std::string>(std::move(text));
 }
 
@@ -243,15 +242,22 @@ int Trim_Single::trim_main()
         int last_read_position = 0; // counts across batches in SE (src/trim_single.cpp:238)
         Batch *batch;
         while (raw.pop(batch) && batch) {
-            Work *w = new Work();
-            w->batch = batch;
+            std::shared_ptr<Frame> frame = std::make_shared<Frame>();
+            frame->batch = batch;
             const size_t n = (size_t)batch->n_lines() / 4;
-            w->reads.resize(n);
+            frame->all.resize(n);
             const int base = last_read_position;
-            frame_records(w->reads, *batch, n, [](size_t i) { return 4 * i; },
+            frame_records(frame->all, *batch, n, [](size_t i) { return 4 * i; },
                           [base](size_t i) { return base + (int)i + 1; });
             last_read_position += (int)n;
-            parsed.push(w);
+            const size_t step = std::max<size_t>(1, piece_reads());
+            for (size_t lo = 0; lo < n; lo += std::min(step, n - lo)) {
+                const size_t hi = lo + std::min(step, n - lo);
+                Work *w = new Work();
+                w->frame = frame;
+                w->reads = Span<FQEntry>(frame->all.data() + lo, hi - lo);
+                parsed.push(w);
+            }
         }
         parsed.close();
     });

@@ -16,9 +16,14 @@ public:
     void close_streams();
 
 private:
-    struct Work {
+    struct Frame { // one ingest batch, framed: owns the text and the record array
         Batch *batch = nullptr;
-        RawVec<FQEntry> reads;
+        RawVec<FQEntry> all;
+        ~Frame() { delete batch; }
+    };
+    struct Work { // a whole frame, or at -a 1 a piece of one (trim.h: piece_reads)
+        std::shared_ptr<Frame> frame;
+        Span<FQEntry> reads;
         std::vector<cutsites> cuts;
     };
     // builds the output text of one batch, in pieces, in file order; updates the counters

@@ -79,13 +79,13 @@ def summary_block(stdout_text):
     return "\n".join(keep).strip("\n")
 
 
-def check_run(binary, tmp, name, rec, summary=True):
+def check_run(binary, tmp, name, rec, summary=True, env=None):
     """Replays one golden run; returns nothing, asserts."""
     for o in rec["outputs"]:
         p = os.path.join(str(tmp), o)
         if os.path.exists(p):
             os.remove(p)
-    pr = run_cli(binary, tmp, rec["argv"])
+    pr = run_cli(binary, tmp, rec["argv"], env=env)
     assert pr.returncode == rec["rc"], (name, pr.returncode, pr.stderr[-500:])
     for o, meta in rec["outputs"].items():
         p = os.path.join(str(tmp), o)

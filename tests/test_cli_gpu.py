@@ -30,6 +30,12 @@ def test_reference_runs_byte_identical_on_gpu(workdir, name):
     cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name])
 
 
+@pytest.mark.parametrize("name", sorted(cu.e2e()["runs"].keys()))
+def test_reference_runs_in_pieces_on_gpu(workdir, name):
+    """An ingest batch cut into pieces of 7 records (3 pairs) for the device and the writers: same bytes."""
+    cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_SUBBATCH_READS": "7"})
+
+
 def test_se_on_gpu_equals_selfpaired_reference(workdir):
     rec = cu.e2e()["runs"]["se_equiv_selfpair_illumina"]
     out = os.path.join(str(workdir), "se_self.fastq")

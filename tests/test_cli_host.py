@@ -31,6 +31,14 @@ def test_reference_runs_byte_identical(hostcheck, workdir, name):
     cu.check_run(hostcheck, workdir, name, cu.e2e()["runs"][name])
 
 
+@pytest.mark.parametrize("piece", [2, 7, 500])
+@pytest.mark.parametrize("name", sorted(cu.e2e()["runs"].keys()))
+def test_reference_runs_in_pieces(hostcheck, workdir, name, piece):
+    """At -a 1 an ingest batch goes through the device and the writers in pieces (host/trim.h: piece_reads);
+    forced tiny here: same bytes, same summary (incl. the PE "Total" of the last INGEST batch)."""
+    cu.check_run(hostcheck, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_SUBBATCH_READS": str(piece)})
+
+
 def se_expected(path, qt, q=20, l=20, no5=False, trunc_n=False, threads=1, batch_lines=None):
     """SE expectation = the oracle's cuts + the record format (`sickle se` itself crashes in the
     reference).  With threads > 1 the per-batch queue-major order is applied by the test."""
