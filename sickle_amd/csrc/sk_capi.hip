@@ -155,6 +155,9 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->scan_id = 0;
     a->team_rbuf = 0;
     a->team_maxlen = 0;
+    a->stream_nb = 0;
+    a->span_reads = 0;
+    a->stream_tbl = 0;
     return SK_OK;
 }
 
@@ -175,6 +178,19 @@ uint32_t rag_buf_bytes(uint64_t max_len, bool uniform)
 
 // which path a batch takes: 3 segmented, 1 tiled (aligned rows), 5 tiled (rows at any address),
 // 2 general kernel only
+// The general kernel: teams of 16 lanes with the reads resident (sk_team.hip) up to SK_STREAM_MIN bytes of the
+// caller's longest-read hint, the streaming wave-per-read kernel (sk_stream.hip) beyond and when there is no
+// hint.  SK_GENERAL=team|stream forces one (diagnostics, tests).
+hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets, const uint32_t *lengths, sk_cut_dev *out,
+                          unsigned long long *errword, const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
+{
+    const char *force = getenv("SK_GENERAL");
+    static const uint64_t stream_min = [] { const char *e = getenv("SK_STREAM_MIN"); return e ? (uint64_t)atoll(e) : 4096ull; }();
+    const bool use_stream = force ? force[0] == 's' : (max_len == 0 || max_len > stream_min);
+    return use_stream ? sk_launch_stream(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream)
+                      : sk_launch_team(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
+}
+
 int path_of(const sk_batch *b)
 {
     if (b->tiles) return 3;
@@ -215,9 +231,9 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)
-        if (ragged) SK_HIP(ctx, sk_launch_team(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, b->stride, ctx->cu_count, stream));
+        if (ragged) SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, b->stride, ctx->cu_count, stream));
     } else {
-        SK_HIP(ctx, sk_launch_team(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->read_len, ctx->cu_count, stream));
+        SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->read_len, ctx->cu_count, stream));
     }
     return SK_OK;
 }

@@ -50,6 +50,9 @@ struct sk_scan_args {
     uint64_t scan_id;     // number of this scan on its error word (ragged batches: tile kernel -> general kernel hand-over)
     uint32_t team_rbuf;   // general kernel: LDS bytes of one read's buffer
     uint32_t team_maxlen; // general kernel: the longest read that goes through LDS
+    uint32_t stream_nb;   // streaming general kernel: 1 KiB blocks in a wave's ring
+    uint32_t span_reads;  // streaming general kernel: consecutive reads a wave takes at a time
+    uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
 };
 
 // internal to libsickle_amd.so (not part of the C ABI)
@@ -64,6 +67,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                      const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                       const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
+                                       const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream);

@@ -1,0 +1,492 @@
+// sk_stream.hip -- the general kernel for long reads: a wave per read, the read STREAMED through a ring of
+// 1 KiB blocks in LDS; see the block comment below.
+#include "sk_kernel_common.h"
+
+// ------------------------------------------------------------------------------------------
+// sk_scan_stream_kernel: reads of any length (reference src/trim.cpp:3-116), one wave per read, no read
+// ever resident as a whole.
+//
+// sk_scan_team_kernel stages a read whole, waits, scans: its LDS buffer is as long as the longest read
+// (5 waves per CU at 30 kb), and every read pays its load latency in full.  Here a wave owns a SPAN of
+// consecutive reads and a ring of NB blocks of 1 KiB; block b of a read = its bytes [1024 b, 1024 b + 1024),
+// fetched by ONE LDS-DMA instruction (16 bytes per lane, the source address per lane: a read starts a block
+// wherever it lies in the batch).  The blocks of the span -- read after read, with -n a read's sequence
+// blocks after its quality blocks -- form one sequence; the DMA runs SK_STREAM_DEPTH blocks ahead of the
+// scan with counted waits (s_waitcnt vmcnt(n): loads return in order), across read boundaries, so the
+// pipeline only drains at the end of a span.  10 KiB of LDS per wave at 30 kb: 16 waves per CU.
+//
+// The scan of a quality block (lane t holds chunk k = 64 b + t, the bytes [16 k, 16 k + 16)):
+//   1. range check (two v_sad_u8 per dword) and chunk sum; a wave prefix scan turns the sums into
+//      P16[k] = sum of the read's bytes before 16 k, kept in a table ring beside the blocks;
+//   2. the window that ENDS in chunk k and starts on a multiple of 16: i = 16 a, a = k - (w >> 4):
+//      S_i - T = P16[k] + (first w & 15 bytes of the chunk) - P16[a] - T =: v_a.  One per lane, exact.
+//   3. the 15 windows between two aligned ones differ from them by at most 8 steps of at most
+//      qmax - qmin each (chars in range; a char out of range among the bytes the reference reads is an
+//      error whatever the cut): if v_{a-1} and v_a lie on one side of 0 by 8 (qmax - qmin) or more, so do
+//      all windows between them.  Two ballots give the cells that may hold the first window at/above the
+//      threshold and the first one below it; only those are evaluated window by window (16 lanes, byte
+//      differences, a DPP row scan): normally two cells per read.
+//   4. the read's state (looking for the first S >= T; for the first S < T after it; done) is wave-uniform
+//      and steps through the flagged cells in order; trim.cpp:46-51 and :65-70 (the first char at/above
+//      resp. below the threshold inside the window) read the ring 64 bytes at a time.
+// The trailing bytes a cell needs lie w + 16 behind the block being scanned: NB = depth + 2 + ceil((w + 16)
+// / 1024) blocks, sized by the launcher from the caller's longest-read hint; a read whose window does not
+// fit is scanned from global memory by the whole wave (scan_read_global: correctness path).
+// With a.buf_bytes != 0 the kernel takes only the 64-read tiles sk_scan_tile_any_kernel left.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int sfirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t sfirst64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// inclusive prefix sum over the wave, six DPP adds: within the rows, then lane 15 of row 0 / 2 into rows 1 / 3,
+// then lane 31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31
+    return v;
+}
+
+// A wave-uniform value kept in a vector register: the kernel's uniform state does not fit the scalar file, and
+// what only the vector ALU reads (masks, thresholds) need not compete for it (nor for the one scalar operand
+// a VOP3 instruction may have).
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t s)
+{
+    uint32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// s_waitcnt vmcnt(min(n, N)) with at most N + 1 cases (n is wave-uniform; waiting for fewer is always safe)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_upto(int n)
+{
+    if constexpr (N == 0) {
+        wait_vmcnt_imm<0>();
+    } else {
+        if (n >= N) wait_vmcnt_imm<N>();
+        else wait_vmcnt_upto<N - 1>(n);
+    }
+}
+
+} // namespace
+
+// DEPTH = blocks in flight ahead of the one being scanned
+template <bool HAS_SEQ, int DEPTH>
+__global__ void __launch_bounds__(64)
+sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                      const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
+                      sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x; // single-wave workgroups
+    const int NB = (int)a.stream_nb;
+    const uint32_t ring_bytes = (uint32_t)NB * 1024u;
+    // P16 of the chunks behind the scan, indexed by chunk number modulo the table size (a power of two)
+    uint32_t *table = reinterpret_cast<uint32_t *>(lds + ring_bytes);
+    const uint32_t tmask4 = in_vgpr((a.stream_tbl - 1u) << 2);
+    const uint64_t batch_end = a.n_reads ? rag_batch_end(offsets, lengths, a) : 0;
+    const int maxw = (NB - DEPTH - 2) * 1024 - 16; // the widest window whose trailing bytes stay in the ring
+    const uint32_t min4 = in_vgpr(splat((uint32_t)a.qmin)), max4 = in_vgpr(splat((uint32_t)a.qmax));
+    const uint32_t hi4 = splat((uint32_t)(127 - a.qmax));
+    const int range = a.qmax - a.qmin;
+    const int B8 = (int)in_vgpr((uint32_t)(8 * range));
+    const uint32_t clean = in_vgpr((uint32_t)(16 * range)); // the range-check sum of a chunk without a char out of range
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+
+    auto locate = [&](uint64_t r, uint64_t &o, int &L) { // wave-uniform
+        uint64_t e;
+        if (offsets) {
+            o = offsets[r];
+            e = offsets[r + 1];
+        } else {
+            o = r * a.stride;
+            e = o + (lengths ? min(lengths[r], a.stride) : a.read_len);
+        }
+        o = sfirst64(o);
+        L = sfirst(e >= o ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0);
+    };
+    auto window_of = [](int L) { const int w = L / 10; return w ? w : L; }; // trim.cpp:8, :30
+    auto streamed = [&](int L) { return L > 0 && L >= a.lthr && window_of(L) <= maxw; };
+
+    // The units of work: spans of a.span_reads consecutive reads, or (a.buf_bytes != 0) the runs of 8 reads of
+    // the 64-read tiles sk_scan_tile_any_kernel left -- if it left any: it has put this scan's number into the
+    // word after the error word for every tile it skipped.  Runs rather than tiles so that the reads of one
+    // left-over tile spread over the device; a wave asks the question for the tile its run lies in.
+    const bool leftovers = a.buf_bytes != 0;
+    if (leftovers && *reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
+    const uint64_t per = leftovers ? 8 : (a.span_reads ? a.span_reads : 1);
+    const uint64_t n_units = (a.n_reads + per - 1) / per;
+
+    uint32_t pbase = 0, cbase = 0; // ring byte offsets of the next block to load / the block being scanned
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint64_t lo = unit * per, hi = min(a.n_reads, lo + per);
+        if (leftovers) {
+            const sk_rag_tile pr_ = rag_probe(lo >> 6, lane, offsets, lengths, a);
+            if (rag_tile_fits(pr_, a.buf_bytes)) continue;
+        }
+        // ---- the loader: a cursor over the blocks of the span, DEPTH ahead of the scan.  Per lane: where its
+        // next chunk comes from and how many bytes of the read are left from there.
+        uint64_t pr = lo;
+        int pact = 1, pseek = 1;
+        int pslow = 0; // the read's last chunk leaves the batch (careful loads), or its last block is empty
+        int pk = 0, pleft = 0; // blocks left of the read's current stream (quality, then the sequence)
+        uint64_t po = 0;
+        int pL = 0;
+        const uint8_t *psrc = nullptr;
+        int prem = 0;
+        int ahead = 0; // blocks issued and not yet scanned
+        auto issue = [&]() {
+            if (pseek) { // the first read at or after pr that goes through the ring
+                pseek = 0;
+                pact = 0;
+                while (pr < hi) {
+                    locate(pr, po, pL);
+                    if (streamed(pL)) {
+                        pk = 0;
+                        pleft = (pL >> 10) + 1; // chunk index L >> 4 included: the window that ends with the read may end there
+                        // that block is empty if L is a multiple of 1024; or the read's last chunk leaves the batch
+                        pslow = ((pL & 1023) == 0 || po + (((uint64_t)pL + 15u) & ~15ull) > batch_end) ? 1 : 0;
+                        psrc = qual + po + lane16;
+                        prem = pL - (int)lane16;
+                        pact = 1;
+                        break;
+                    }
+                    ++pr;
+                }
+            }
+            if (!pact) return;
+            uint8_t *dst = lds + pbase;
+            if (!pslow) {
+                if (prem > 0) __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)dst, 16, 0, SK_DMA_AUX);
+            } else if (pk == 0 && pleft == 1 && (pL & 1023) == 0) { // nothing to load, but one DMA per block keeps the count
+                if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)(qual + po), (lptr_t)dst, 16, 0, SK_DMA_AUX);
+            } else if (prem > 0) {
+                if (prem >= 16 || (uint64_t)(psrc - (HAS_SEQ && pk ? seq : qual)) + 16u <= batch_end) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)dst, 16, 0, SK_DMA_AUX);
+                } else { // the batch ends inside this chunk: byte by byte
+                    for (int q = 0; q < prem; ++q) dst[lane16 + (uint32_t)q] = psrc[q];
+                }
+            }
+            ++ahead;
+            pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
+            psrc += 1024;
+            prem -= 1024;
+            if (--pleft == 0) {
+                if (HAS_SEQ && pk == 0) {
+                    pk = 1;
+                    pleft = (pL + 1023) >> 10;
+                    psrc = seq + po + lane16;
+                    prem = pL - (int)lane16;
+                } else {
+                    ++pr;
+                    pseek = 1;
+                }
+            }
+        };
+        // the scan's block has arrived when every load but those issued after it has returned
+        auto arrive = [&]() {
+            issue();
+            wait_vmcnt_upto<DEPTH>(--ahead);
+        };
+        auto leave = [&]() {
+            // every LDS read of this block is done before the loader comes round to its slot again
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cbase = cbase + 1024u == ring_bytes ? 0u : cbase + 1024u;
+        };
+#pragma unroll 1
+        for (int d = 0; d < DEPTH; ++d) issue();
+
+#pragma unroll 1
+        for (uint64_t r = lo; r < hi; ++r) {
+            uint64_t o;
+            int L;
+            locate(r, o, L);
+            if (!(L > 0 && L >= a.lthr)) { // trim.cpp:21
+                if (lane == 0) out[r] = sk_cut_dev{-1, -1};
+                continue;
+            }
+            const int w = window_of(L);
+            if (w > maxw) { // the window does not fit the ring: from global memory
+                const sk_cut_dev cut = scan_read_global<HAS_SEQ>(qual + o, HAS_SEQ ? seq + o : nullptr, L, r, lane, a, errword);
+                if (lane == 0) out[r] = cut;
+                continue;
+            }
+            const int wq = w >> 4, wr = w & 15;
+            const int nwin = L - w + 1;
+            const int T = (int)in_vgpr((uint32_t)(a.craw * w));
+            const uint32_t wq4 = in_vgpr(4u * (uint32_t)wq);
+            const int nbq = (L >> 10) + 1;
+            uint32_t pm[4]; // the first wr bytes of a chunk
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = wr - 4 * u;
+                pm[u] = in_vgpr(n >= 4 ? ~0u : (n <= 0 ? 0u : (1u << (8 * n)) - 1u));
+            }
+            // blocks [jf0, jf1): every lane's aligned window exists, has one before it, and ends inside the read
+            const int jf0 = (wq + 64) >> 6, jf1 = (L - 15) >> 10;
+            const uint32_t nfast = (uint32_t)max(0, jf1 - jf0);
+            const int jtail = (((nwin - 1) >> 4) + wq) >> 6; // the block the last aligned window ends in
+            int phase = a.no5 ? 1 : 0; // 0: looking for the first S >= T (trim.cpp:42), 1: for the first S < T after it (:61), 2: done
+            int i0 = INF, i1 = INF, five = 0, three = L;
+            uint32_t carry = 0; // sum of the read's bytes before the block
+            int vprev = 0, vtail = 0;
+            int pb = INF, pbch = 0; // first char out of range
+            int j = 0;              // the block being scanned
+            uint32_t k4 = 4u * (uint32_t)lane; // 4 * this lane's chunk number
+
+            // byte at read position p, which lies in block j or up to NB - DEPTH - 1 blocks before it
+            auto ringbyte = [&](int p) -> int {
+                int at = (int)cbase - ((j - (p >> 10)) << 10);
+                if (at < 0) at += (int)ring_bytes;
+                return (int)lds[(uint32_t)at + (uint32_t)(p & 1023)];
+            };
+            // the first char at/above (below) the threshold from `from` on, inside the window that starts there
+            // (it ends at or before the block being scanned)
+            auto first_char = [&](int from, bool above) -> int {
+                for (int g0 = 0; g0 < w; g0 += 64) {
+                    const bool in = g0 + lane < w;
+                    const int c = in ? ringbyte(from + g0 + lane) : 0;
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(in && ((c >= a.cthr_raw) == above));
+                    if (m) return from + g0 + __builtin_ctzll(m);
+                }
+                return INF;
+            };
+            // One cell: the windows base + 1 .. base + cnt given Sb = S_base - T (cnt == 0: window 0 alone, Sb its
+            // S - T), trim.cpp:34-81 over them in order
+            auto cell = [&](int base, int Sb, int cnt) {
+                uint32_t ge, vm;
+                if (cnt == 0) {
+                    ge = Sb >= 0 ? 1u : 0u;
+                    vm = 1u;
+                } else {
+                    const int u = lane & 15;
+                    int dl = 0;
+                    if (u < cnt) dl = ringbyte(base + w + u) - ringbyte(base + u); // trim.cpp:76-80
+                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x111, 0xf, 0xf, true); // inclusive scan over the row
+                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x112, 0xf, 0xf, true);
+                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x114, 0xf, 0xf, true);
+                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x118, 0xf, 0xf, true);
+                    ge = (uint32_t)__builtin_amdgcn_ballot_w64(Sb + dl >= 0) & 0xffffu; // bit u: S_{base + 1 + u} >= T
+                    vm = (1u << cnt) - 1u;
+                }
+                uint32_t lt = ~ge & vm;
+                if (phase == 0) {
+                    lt = 0;
+                    const uint32_t g = ge & vm;
+                    if (g) {
+                        const int u0 = __builtin_ctz(g);
+                        i0 = base + 1 + u0;
+                        phase = 1;
+                        lt = ~ge & vm & ~((2u << u0) - 1u);
+                        five = first_char(i0, true); // trim.cpp:46-51
+                        if (five == INF) five = 0;
+                    }
+                }
+                if (phase == 1 && lt) {
+                    i1 = base + 1 + __builtin_ctz(lt);
+                    phase = 2;
+                    three = first_char(i1, false); // trim.cpp:65-70
+                    if (three == INF) three = L;
+                }
+            };
+
+#pragma unroll 1
+            for (j = 0; j < nbq; ++j, k4 += 256u) {
+                arrive();
+                if (phase < 2) {
+                    const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
+                    bool event = true;
+                    if (phase == 1 && (uint32_t)(j - jf0) < nfast) {
+                        // ---- the usual block: inside the read, past the first window, looking for the first S < T.
+                        // Nothing happens in it if every aligned window and its predecessor are 8 (qmax - qmin)
+                        // or more above the threshold and every char is in range.
+                        uint32_t sad = 0, sum = 0, part = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            sad = __builtin_amdgcn_sad_u8(d[u], min4, sad);
+                            sad = __builtin_amdgcn_sad_u8(d[u], max4, sad);
+                            sum = __builtin_amdgcn_sad_u8(d[u], 0u, sum);
+                            part = __builtin_amdgcn_sad_u8(d[u] & pm[u], 0u, part);
+                        }
+                        const uint32_t incl = wave_scan_add(sum);
+                        const uint32_t P = carry + incl - sum; // the bytes before this chunk
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = P;
+                        const uint32_t Pa = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table) + ((k4 - wq4) & tmask4));
+                        const int v = (int)(P + part - Pa) - T;
+                        const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false); // wave_shr:1
+                        const bool quiet = min(v, vp) >= B8 && sad == clean;
+                        if (__builtin_amdgcn_ballot_w64(!quiet) == 0) {
+                            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            vprev = __builtin_amdgcn_readlane(v, 63);
+                            if (j == jtail) vtail = __builtin_amdgcn_readlane(v, (((nwin - 1) >> 4) + wq) & 63);
+                            event = false;
+                        }
+                    }
+                    if (event) {
+                        const int k = 64 * j + lane, x = 16 * k;
+                        uint32_t sad = 0, sum = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = L - x - 4 * u;
+                            const uint32_t xq = first_bytes(d[u], n, min4);
+                            sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+                            sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+                            sum = __builtin_amdgcn_sad_u8(first_bytes(d[u], n, 0u), 0u, sum);
+                        }
+                        const bool bad = sad != clean; // fillers are legal chars
+                        const uint32_t incl = wave_scan_add(sum);
+                        const uint32_t P = carry + incl - sum; // the bytes before x
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = P;
+                        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+
+                        // the aligned window that ends in this chunk
+                        const int ai = k - wq;
+                        const bool val = ai >= 0 && x + wr <= L;
+                        uint32_t part = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) part = __builtin_amdgcn_sad_u8(d[u] & pm[u], 0u, part);
+                        int v = 0;
+                        if (val) v = (int)(P + part - *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table) + ((k4 - wq4) & tmask4))) - T;
+                        // v of the aligned window before: the lane to the left, lane 0 from the block before (wave_shr:1)
+                        const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false);
+                        const bool first = ai == 0;
+                        const bool cge = first ? v >= 0 : (v >= B8 && vp >= B8); // every window of the cell at/above the threshold
+                        const bool clt = first ? v < 0 : (v < -B8 && vp < -B8); // every window of the cell below it
+                        const uint64_t m_ge = __builtin_amdgcn_ballot_w64(val && !clt);
+                        const uint64_t m_lt = __builtin_amdgcn_ballot_w64(val && !cge);
+                        vprev = __builtin_amdgcn_readlane(v, 63);
+                        if (j == jtail) vtail = __builtin_amdgcn_readlane(v, (((nwin - 1) >> 4) + wq) & 63);
+                        if (__builtin_amdgcn_ballot_w64(bad) && pb == INF) { // trim.cpp:129: where, and which char
+                            int p = INF;
+                            if (bad) {
+#pragma unroll
+                                for (int u = 3; u >= 0; --u) {
+                                    const uint32_t f = keep_first(bad_flags(d[u], min4, hi4), L - x - 4 * u);
+                                    if (f) p = x + 4 * u + (__builtin_ctz(f) >> 3);
+                                }
+                            }
+                            pb = wave_min(p);
+                            pbch = (int)(int8_t)ringbyte(pb);
+                        }
+                        int cur = 0;
+                        while (phase < 2 && cur < 64) {
+                            const uint64_t m = (phase == 0 ? m_ge : m_lt) & (~0ull << cur);
+                            if (!m) break;
+                            const int t = __builtin_ctzll(m);
+                            const int at = 64 * j + t - wq;
+                            if (at == 0) cell(-1, __builtin_amdgcn_readlane(v, t), 0);
+                            else cell(16 * (at - 1), __builtin_amdgcn_readlane(vp, t), 16);
+                            cur = t + 1;
+                        }
+                    }
+                }
+                if (j + 1 < nbq) leave();
+            }
+            j = nbq - 1;
+            if (phase < 2) { // the windows after the last aligned one
+                const int alast = (nwin - 1) >> 4, rem = nwin - 1 - 16 * alast;
+                if (rem > 0) {
+                    const bool none = phase == 0 ? vtail < -rem * range : vtail >= rem * range;
+                    if (!none) cell(16 * alast, vtail, rem);
+                }
+            }
+            const int touched = phase == 2 ? i1 + w : L;
+            if (pb < touched && lane == 0) report_error(errword, r, pb, pbch);
+            leave();
+
+            if (HAS_SEQ) { // trim.cpp:86-98
+                uint32_t nlo = NONE, anyN = 0; // bit index of the first lowercase n; any uppercase N
+                const int nbs = (L + 1023) >> 10;
+#pragma unroll 1
+                for (j = 0; j < nbs; ++j) {
+                    arrive();
+                    const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
+                    const int x = 16 * (64 * j + lane);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t xx = first_bytes(d[u], L - x - 4 * u, 0u);
+                        const uint32_t y = (xx | 0x20202020u) ^ 0x6e6e6e6eu;
+                        const uint32_t either = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & H4;
+                        const uint32_t lower = either & (xx << 2); // bit 5 of the byte moved onto its flag
+                        nlo = min(nlo, __builtin_elementwise_add_sat(ffbl_or_none(lower), (uint32_t)(8 * (x + 4 * u))));
+                        anyN |= either ^ lower;
+                    }
+                    leave();
+                }
+                const int nl = wave_min(nlo == NONE ? INF : (int)(nlo >> 3));
+                anyN = wave_or(anyN);
+                if (nl != INF) three = nl - 1;
+                else if (anyN) three = -2;
+            }
+            const bool found5 = a.no5 || i0 != INF;
+            if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
+                five = -1;
+                three = -1;
+            }
+            if (lane == 0) out[r] = sk_cut_dev{five, three};
+        }
+    }
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                       const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
+                                       const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
+{
+    // max_len = the longest read the caller expects (0 = unknown): sizes the ring; longer reads still come out
+    // right, from global memory (scan_read_global)
+    if (a->n_reads == 0) return hipSuccess;
+    if (max_len == 0) max_len = 32768;
+    const uint64_t wmax = max_len >= 10 ? max_len / 10 : max_len;
+    uint64_t back = 2 + (wmax + 16 + 1023) / 1024; // blocks behind the loader: the one being scanned and the window's trailing bytes
+    if (back > 60) back = 60;
+    static const int depth_env = [] { const char *e = getenv("SK_STREAM_DEPTH"); return e ? atoi(e) : 0; }();
+    int depth = depth_env ? depth_env : 8;
+    if (depth != 4 && depth != 8 && depth != 12 && depth != 16) depth = 8;
+    sk_scan_args at = *a;
+    at.stream_nb = (uint32_t)(back + depth);
+    uint32_t tbl = 64;
+    while (tbl < 64u * (uint32_t)(back + 1)) tbl <<= 1;
+    at.stream_tbl = tbl;
+    const uint32_t lds_bytes = at.stream_nb * 1024u + tbl * 4u;
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    static const int wave_cap = [] { const char *e = getenv("SK_STREAM_WAVES"); return e ? atoi(e) : 16; }();
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    // spans of consecutive reads, a few per wave (the pipeline drains between spans; short spans balance better)
+    static const uint64_t spans_per_wave = [] { const char *e = getenv("SK_STREAM_SPANS"); return e ? (uint64_t)atoll(e) : 8ull; }();
+    uint64_t per = a->n_reads / (grid * spans_per_wave);
+    if (per < 1) per = 1;
+    if (per > 64) per = 64;
+    at.span_reads = (uint32_t)per;
+    const uint64_t n_units = a->buf_bytes ? (a->n_reads + 7) / 8 : (a->n_reads + per - 1) / per;
+    if (grid > n_units) grid = n_units;
+    if (grid == 0) return hipSuccess;
+    auto launch = [&](auto kern) {
+        const kernel_facts facts = prepare_kernel(kern);
+        if (facts.status != hipSuccess) return facts.status;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
+                           errword, at);
+        return hipGetLastError();
+    };
+    auto pick = [&](auto seqtag) {
+        constexpr bool S = decltype(seqtag)::value;
+        switch (depth) {
+        case 4: return launch(sk_scan_stream_kernel<S, 4>);
+        case 12: return launch(sk_scan_stream_kernel<S, 12>);
+        case 16: return launch(sk_scan_stream_kernel<S, 16>);
+        default: return launch(sk_scan_stream_kernel<S, 8>);
+        }
+    };
+    return a->truncn ? pick(std::true_type{}) : pick(std::false_type{});
+}

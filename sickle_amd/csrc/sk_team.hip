@@ -23,124 +23,6 @@
 // wave (scan_read_global: the same algorithm byte by byte; correctness path).
 // With a.buf_bytes != 0 the kernel takes only the 64-read tiles sk_scan_tile_any_kernel left.
 // ------------------------------------------------------------------------------------------
-namespace {
-
-template <int TEAM>
-__device__ __forceinline__ int team_min(int v) // teams of 16 lanes are DPP rows
-{
-    return TEAM == 16 ? row_min(v) : wave_min(v);
-}
-template <int TEAM>
-__device__ __forceinline__ uint32_t team_or(uint32_t v)
-{
-    return TEAM == 16 ? row_or(v) : wave_or(v);
-}
-template <int TEAM>
-__device__ __forceinline__ uint32_t team_scan_add(uint32_t v, int tl) // inclusive prefix sum over the team
-{
-    // within a row: row_shr:n reads the lane n to the left, lanes without one add nothing (bound_ctrl: 0)
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    if (TEAM == 64) { // the rows before this lane's: their totals through scalar registers
-        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
-                       t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
-        const int row = tl >> 4;
-        v += row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2;
-    }
-    return v;
-}
-
-// one read, the whole wave, from global memory: reference trim.cpp:3-116 with the closed form of this
-// file's header, byte by byte.  Returns the cut (the same value in every lane).
-template <bool HAS_SEQ>
-__device__ __forceinline__ sk_cut_dev scan_read_global(const uint8_t *__restrict__ q, const uint8_t *__restrict__ sq, int L,
-                                                    uint64_t r, int lane, const sk_scan_args &a, unsigned long long *errword)
-{
-    int five = -1, three = -1;
-    if (L > 0 && L >= a.lthr) { // trim.cpp:21
-        int w = L / 10;
-        if (w == 0) w = L;
-        const int nwin = L - w + 1;
-        const int T = a.craw * w;
-
-        // first bad char of the whole read (lanes stride the bytes, coalesced)
-        int pbad = INF;
-        for (int j = lane; j < L; j += 64) {
-            const int c = (int)(int8_t)q[j];
-            if ((c < a.qmin || c > a.qmax) && pbad == INF) pbad = j;
-        }
-        pbad = wave_min(pbad);
-
-        // lane owns windows [s, e): seeds the sum, then rolls it (trim.cpp:76-80)
-        const int per = (nwin + 63) >> 6;
-        const int s = lane * per;
-        const int e = min(nwin, s + per);
-        int fa = INF, fb = INF, fc = INF; // first >=T, first <T, first <T after fa
-        if (s < e) {
-            int tot = 0;
-            for (int j = 0; j < w; ++j) tot += q[s + j];
-            for (int i = s; i < e; ++i) {
-                if (tot >= T) {
-                    if (fa == INF) fa = i;
-                } else {
-                    if (fb == INF) fb = i;
-                    if (fa != INF && fc == INF) fc = i;
-                }
-                if (i + 1 < e) tot += (int)q[i + w] - (int)q[i];
-            }
-        }
-        const int i0 = a.no5 ? -1 : wave_min(fa);
-        const bool found5 = a.no5 || i0 != INF;
-        int cand = INF;
-        if (a.no5) cand = fb;
-        else if (i0 != INF && s < e) cand = (s > i0) ? fb : (fa == i0 ? fc : INF);
-        const int i1 = wave_min(cand);
-        const bool done = found5 && i1 != INF;
-
-        five = 0;
-        three = L;
-        if (!a.no5 && i0 != INF) { // trim.cpp:46-51
-            int hit = INF;
-            for (int j = lane; j < w && hit == INF; j += 64)
-                if ((int)q[i0 + j] >= a.cthr_raw) hit = i0 + j;
-            five = wave_min(hit);
-            if (five == INF) five = 0;
-        }
-        if (done) { // trim.cpp:65-70
-            int hit = INF;
-            for (int j = lane; j < w && hit == INF; j += 64)
-                if ((int)q[i1 + j] < a.cthr_raw) hit = i1 + j;
-            three = wave_min(hit);
-            if (three == INF) three = L;
-        }
-        const int touched = done ? i1 + w : L;
-        if (pbad < touched) {
-            if (lane == 0) report_error(errword, r, pbad, (int)(int8_t)q[pbad]);
-        }
-        if (HAS_SEQ) { // trim.cpp:86-98
-            int ni = INF, Ni = INF;
-            for (int j = lane; j < L; j += 64) {
-                const uint8_t c = sq[j];
-                if (c == 'n' && ni == INF) ni = j;
-                if (c == 'N' && Ni == INF) Ni = j;
-            }
-            ni = wave_min(ni);
-            Ni = wave_min(Ni);
-            if (ni != INF) three = ni - 1;
-            else if (Ni != INF) three = -2;
-        }
-        if (!found5 || (three - five < a.lthr)) { // trim.cpp:103-108
-            five = -1;
-            three = -1;
-        }
-    }
-    return sk_cut_dev{five, three};
-}
-
-} // namespace
-
 template <int TEAM, bool HAS_SEQ>
 __global__ void __launch_bounds__(64)
 sk_scan_team_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
