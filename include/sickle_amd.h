@@ -25,8 +25,9 @@
  *                 (0 = unknown), which sizes the kernel's LDS tiles (sk_submit / sk_trim_batch see
  *                 the offsets and work it out themselves).  Tiles of 64 consecutive reads are
  *                 re-strided on their way into LDS and scanned one lane per read; a tile whose
- *                 reads are too long for that (and the last tile of the batch) goes to the general
- *                 kernel.
+ *                 reads are too long for that goes to the general kernel (a wave per read, the read
+ *                 streamed through LDS: any length).  A hint beyond 4096 declares a long-read batch:
+ *                 the general kernel takes all of it, in spans of equal cost per wave.
  *   fixed stride: offsets == NULL; read r = bytes [r*stride, r*stride + len_r) with
  *                 len_r = lengths ? lengths[r] : read_len.  Fastest: stride % 8 == 0, stride <=
  *                 SK_TILE_MAX_STRIDE, base pointers 16-byte aligned, stride/8 ODD (152, 104, 264
@@ -200,7 +201,8 @@ int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
- * 2 = general (wave per read), 3 = tiled over a segmented batch, 4 = tiled with the tile staged
+ * 2 = general (teams of 16 lanes per read up to a longest read of 4096, 6 = a wave per read with the read
+ * streamed through LDS beyond), 3 = tiled over a segmented batch, 4 = tiled with the tile staged
  * through registers (equal lengths, no sequence buffer, row stride 72..160), 5 = tiled with rows
  * re-strided on the way into LDS (packed / misaligned fixed stride, ragged).  For tests and bench
  * labels. */

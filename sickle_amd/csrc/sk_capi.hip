@@ -208,8 +208,13 @@ bool tile_eligible(const sk_batch *b)
 // enqueue the kernel.  All pointers are device pointers.  The error word is "no error" on
 // entry: it is reset when the context is created and again by whoever reads it
 // (reset_error_word), so nothing but the kernel sits on the launch path.
+// rag_fit (batches with `offsets` or `lengths`): does any 64-read tile fit the tile kernel's LDS buffer?  1 yes, 0 no
+// (the general kernel takes the whole batch in spans of equal cost), -1 not known: sk_submit counts on the host,
+// a device-resident batch is taken for a long-read batch when the caller's longest-read hint is beyond
+// SK_LONG_BATCH_HINT -- 64 CONSECUTIVE reads of at most 2 040 bases do not occur in one.
+#define SK_LONG_BATCH_HINT 4096u
 int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_dev *out, unsigned long long *d_err,
-                 hipStream_t stream)
+                 hipStream_t stream, int rag_fit = -1)
 {
     if (a->n_reads == 0) return SK_OK;
     const uint8_t *seq = a->truncn ? b->seq : nullptr;
@@ -222,6 +227,10 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
     } else if (path == 5) {
         sk_scan_args ar = *a;
         const bool ragged = b->offsets || b->lengths;
+        if (ragged && (rag_fit == 0 || (rag_fit < 0 && b->offsets && b->stride > SK_LONG_BATCH_HINT))) {
+            SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->stride, ctx->cu_count, stream));
+            return SK_OK;
+        }
         // the scans of a context are numbered upwards: the tile kernel leaves the number in the word after
         // the error word when it skips a tile, the general kernel returns at once if it does not find it
         ar.scan_id = ++ctx->scan_counter;
@@ -451,7 +460,13 @@ int sk_kernel_for(const sk_batch *batch)
 {
     if (!batch) return 0;
     if (batch->tiles) return 3;
-    if (!tile_eligible(batch)) return path_of(batch);
+    if (!tile_eligible(batch)) {
+        const int path = path_of(batch);
+        const bool ragged = batch->offsets || batch->lengths;
+        const uint64_t longest = ragged ? batch->stride : batch->read_len;
+        const bool general_only = path == 2 || (path == 5 && batch->offsets && batch->stride > SK_LONG_BATCH_HINT);
+        return general_only ? ((longest == 0 || longest > 4096) ? 6 : 2) : path;
+    }
     // uniform batches without a sequence buffer (no -n) and rows of 72..160 bytes: the tile comes in
     // through the wave's registers instead of LDS-DMA
     if (!batch->lengths && !batch->seq && sk_tile_is_staged(batch->stride, batch->read_len, 0)) return 4;
@@ -512,6 +527,7 @@ const char *sk_kernel_name(int which)
     case 3: return "sk_scan_tile_kernel";
     case 4: return "sk_scan_tile_staged_kernel";
     case 5: return "sk_scan_tile_any_kernel";
+    case 6: return "sk_scan_stream_kernel";
     default: return "";
     }
 }
@@ -614,6 +630,7 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
             }
     }
     uint64_t rag_max_len = 0;
+    int rag_fit = -1;
     if (batch->offsets) {
         // host offsets are checked here (ascending, reads within SK_MAX_READ_LEN: the error word keeps
         // 24 bits of position) and give the exact longest read, which sizes the tile kernel's buffers
@@ -625,6 +642,14 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
                 return SK_EINVAL;
             }
             if (e - o > rag_max_len) rag_max_len = e - o;
+        }
+        // does any tile of 64 consecutive reads fit the tile kernel's buffer (rag_tile_fits of the kernels)?
+        const uint32_t buf = rag_buf_bytes(rag_max_len, false);
+        rag_fit = 0;
+        for (size_t t = 0; t < n && !rag_fit; t += 64) {
+            uint64_t lmax = 0;
+            for (size_t r = t; r < n && r < t + 64; ++r) lmax = std::max<uint64_t>(lmax, batch->offsets[r + 1] - batch->offsets[r]);
+            if (lmax <= SK_RAG_MAX_LEN && 64 * 16 * (((lmax + 15) >> 4) | 1) + SK_TILE_SLACK <= buf) rag_fit = 1;
         }
     }
     rc = grow_slot(ctx, s, bytes, n, a.truncn != 0, batch->offsets != nullptr, batch->lengths != nullptr);
@@ -700,7 +725,7 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
         dev.classes = s.classes.data();
         dev.n_classes = (uint32_t)s.classes.size();
     }
-    rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute);
+    rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute, rag_fit);
     if (rc != SK_OK) return rc;
     if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));
     SK_HIP(ctx, hipMemcpyAsync(s.h_err, s.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->compute));

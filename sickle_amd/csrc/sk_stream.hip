@@ -118,19 +118,62 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
     auto window_of = [](int L) { const int w = L / 10; return w ? w : L; }; // trim.cpp:8, :30
     auto streamed = [&](int L) { return L > 0 && L >= a.lthr && window_of(L) <= maxw; };
 
-    // The units of work: spans of a.span_reads consecutive reads, or (a.buf_bytes != 0) the runs of 8 reads of
-    // the 64-read tiles sk_scan_tile_any_kernel left -- if it left any: it has put this scan's number into the
-    // word after the error word for every tile it skipped.  Runs rather than tiles so that the reads of one
-    // left-over tile spread over the device; a wave asks the question for the tile its run lies in.
+    // The spans.  All reads (a.buf_bytes == 0): ONE span per wave, the batch cut into gridDim.x runs of
+    // consecutive reads of equal cost -- bytes plus a.span_reads bytes per read, found by a search in `offsets`
+    // (a deal of reads by number leaves the slowest of 3 584 waves 45 % over the mean on a 1-30 kb mix); equal
+    // numbers of reads without offsets.  Or (a.buf_bytes != 0) the runs of 8 reads of the 64-read tiles
+    // sk_scan_tile_any_kernel left -- if it left any: it has put this scan's number into the word after the
+    // error word for every tile it skipped.  Runs rather than tiles so that the reads of one left-over tile
+    // spread over the device; a wave asks the question for the tile its run lies in.
     const bool leftovers = a.buf_bytes != 0;
     if (leftovers && *reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
-    const uint64_t per = leftovers ? 8 : (a.span_reads ? a.span_reads : 1);
-    const uint64_t n_units = (a.n_reads + per - 1) / per;
+    uint64_t span_lo = 0, span_hi = 0;
+    if (!leftovers) {
+        const uint64_t g = blockIdx.x, G = gridDim.x, n = a.n_reads;
+        if (offsets) {
+            // cost(r) = offsets[r] - offsets[0] + c r, r in [0, n]: ascending.  The span of wave g starts at the
+            // first r with cost(r) >= g total / G and ends where the next one starts.  Both bounds at once: the
+            // lower half of the wave searches one, the upper half the other, 32 probes per round.
+            const uint64_t c = a.span_reads, base = offsets[0];
+            const uint64_t total = offsets[n] - base + c * n;
+            const int half = lane >> 5, sub = lane & 31;
+            const uint64_t tgt = (g + (uint64_t)half) * total / G; // total < 2^48, G < 2^16
+            uint64_t l_ = 0, h_ = n; // the answer lies in [l_, h_] and cost(h_) >= tgt
+            while (__builtin_amdgcn_ballot_w64(l_ < h_)) {
+                const uint64_t step = (h_ - l_ + 31) / 32;
+                const uint64_t p = min(l_ + (uint64_t)sub * max(step, (uint64_t)1), h_);
+                const bool ge = offsets[p] - base + c * p >= tgt;
+                const uint64_t m64 = __builtin_amdgcn_ballot_w64(ge);
+                const uint32_t m = (uint32_t)(half ? m64 >> 32 : m64);
+                if (l_ < h_) {
+                    if (m == 0) {
+                        l_ = min(l_ + 31 * step + 1, h_);
+                    } else {
+                        const uint64_t f = (uint64_t)__builtin_ctz(m);
+                        if (f == 0) {
+                            h_ = l_;
+                        } else {
+                            h_ = min(l_ + f * step, h_);
+                            l_ = l_ + (f - 1) * step + 1;
+                        }
+                    }
+                }
+            }
+            span_lo = readlane_u64(l_, 0);
+            span_hi = g + 1 == G ? n : readlane_u64(l_, 32);
+        } else {
+            span_lo = n * g / G;
+            span_hi = n * (g + 1) / G;
+        }
+    }
+    const uint64_t n_units = leftovers ? (a.n_reads + 7) / 8 : (uint64_t)blockIdx.x + 1;
 
     uint32_t pbase = 0, cbase = 0; // ring byte offsets of the next block to load / the block being scanned
     for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-        const uint64_t lo = unit * per, hi = min(a.n_reads, lo + per);
+        uint64_t lo = span_lo, hi = span_hi;
         if (leftovers) {
+            lo = unit * 8;
+            hi = min(a.n_reads, lo + 8);
             const sk_rag_tile pr_ = rag_probe(lo >> 6, lane, offsets, lengths, a);
             if (rag_tile_fits(pr_, a.buf_bytes)) continue;
         }
@@ -450,8 +493,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
     uint64_t back = 2 + (wmax + 16 + 1023) / 1024; // blocks behind the loader: the one being scanned and the window's trailing bytes
     if (back > 60) back = 60;
     static const int depth_env = [] { const char *e = getenv("SK_STREAM_DEPTH"); return e ? atoi(e) : 0; }();
-    int depth = depth_env ? depth_env : 8;
-    if (depth != 4 && depth != 8 && depth != 12 && depth != 16) depth = 8;
+    int depth = depth_env ? depth_env : 3;
+    if (depth != 2 && depth != 3 && depth != 4 && depth != 8) depth = 3;
     sk_scan_args at = *a;
     at.stream_nb = (uint32_t)(back + depth);
     uint32_t tbl = 64;
@@ -459,17 +502,16 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
     at.stream_tbl = tbl;
     const uint32_t lds_bytes = at.stream_nb * 1024u + tbl * 4u;
     int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
-    static const int wave_cap = [] { const char *e = getenv("SK_STREAM_WAVES"); return e ? atoi(e) : 16; }();
+    static const int wave_cap = [] { const char *e = getenv("SK_STREAM_WAVES"); return e ? atoi(e) : 24; }();
     if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu > 4) per_cu &= ~3; // the same number of waves on every SIMD (17 per CU measured slower than 16)
     if (per_cu < 1) return hipErrorInvalidValue;
     uint64_t grid = (uint64_t)cu_count * per_cu;
-    // spans of consecutive reads, a few per wave (the pipeline drains between spans; short spans balance better)
-    static const uint64_t spans_per_wave = [] { const char *e = getenv("SK_STREAM_SPANS"); return e ? (uint64_t)atoll(e) : 8ull; }();
-    uint64_t per = a->n_reads / (grid * spans_per_wave);
-    if (per < 1) per = 1;
-    if (per > 64) per = 64;
-    at.span_reads = (uint32_t)per;
-    const uint64_t n_units = a->buf_bytes ? (a->n_reads + 7) / 8 : (a->n_reads + per - 1) / per;
+    // one span of consecutive reads per wave, cut at equal cost: a read counts as its bytes plus this many
+    // (what a read costs beyond its blocks: the first window, the cut searches, the store)
+    static const uint32_t read_cost = [] { const char *e = getenv("SK_STREAM_READ_COST"); return e ? (uint32_t)atoll(e) : 4096u; }();
+    at.span_reads = read_cost;
+    const uint64_t n_units = a->buf_bytes ? (a->n_reads + 7) / 8 : a->n_reads;
     if (grid > n_units) grid = n_units;
     if (grid == 0) return hipSuccess;
     auto launch = [&](auto kern) {
@@ -482,10 +524,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
     auto pick = [&](auto seqtag) {
         constexpr bool S = decltype(seqtag)::value;
         switch (depth) {
+        case 2: return launch(sk_scan_stream_kernel<S, 2>);
+        case 8: return launch(sk_scan_stream_kernel<S, 8>);
         case 4: return launch(sk_scan_stream_kernel<S, 4>);
-        case 12: return launch(sk_scan_stream_kernel<S, 12>);
-        case 16: return launch(sk_scan_stream_kernel<S, 16>);
-        default: return launch(sk_scan_stream_kernel<S, 8>);
+        default: return launch(sk_scan_stream_kernel<S, 3>);
         }
     };
     return a->truncn ? pick(std::true_type{}) : pick(std::false_type{});

@@ -37,7 +37,7 @@ def test_tables_match_reference_constants():
         assert (p[0], p[1], p[2]) == k
     assert [lib.sk_typename(i) for i in range(4)] == [b"Phred", b"Sanger", b"Solexa", b"Illumina"]
     assert not lib.sk_quality_constants(7)
-    assert lib.sk_kernel_name(1) == b"sk_scan_tile_kernel" and lib.sk_kernel_name(2) == b"sk_scan_team_kernel" and lib.sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
+    assert lib.sk_kernel_name(1) == b"sk_scan_tile_kernel" and lib.sk_kernel_name(2) == b"sk_scan_team_kernel" and lib.sk_kernel_name(5) == b"sk_scan_tile_any_kernel" and lib.sk_kernel_name(6) == b"sk_scan_stream_kernel"
 
 
 def test_no_device_means_failure_not_fallback():

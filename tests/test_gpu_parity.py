@@ -55,8 +55,92 @@ def test_kernel_selection():
     b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 0, 0, None, 1)
     assert capi.lib().sk_kernel_for(b) == 5  # ragged: the same kernel, per-lane lengths
     b = capi.Batch(q.ctypes.data, None, None, 600, 600, None, 10)
-    assert capi.lib().sk_kernel_for(b) == 2  # rows beyond the tile kernels: general kernel
+    assert capi.lib().sk_kernel_for(b) == 2  # rows beyond the tile kernels: general kernel (teams of 16 lanes)
     assert capi.lib().sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
+    b = capi.Batch(q.ctypes.data, None, None, 5000, 5000, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 6  # longer than 4096: the streaming general kernel
+    b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 30_000, 0, None, 1)
+    assert capi.lib().sk_kernel_for(b) == 6  # ragged with a longest-read hint beyond 4096: a long-read batch
+    b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 301, 0, None, 1)
+    assert capi.lib().sk_kernel_for(b) == 5
+    assert capi.lib().sk_kernel_name(6) == b"sk_scan_stream_kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["team", "stream"])
+def test_both_general_kernels_on_every_length(sk_ctx, which, monkeypatch):
+    """SK_GENERAL forces one of the two general kernels (teams with the reads resident / a wave per read, the
+    read streamed through a ring of 1 KiB blocks) for every batch that takes the general path: both must agree
+    with the oracle on lengths from 1 to 70 kb -- around the block size (1023..1025, 2047..2049), multiples of
+    1024 (the empty last block), 16 k + 0..15 (the partial last chunk), windows of every residue modulo 16 --
+    with cuts at the very start, in the middle and in the last windows, device-resident ragged (all reads, spans of
+    equal cost), through sk_submit (the host counts the tiles that fit), as left-overs behind the tile kernel, and
+    as uniform fixed-stride batches; with -x, -n and a range error."""
+    monkeypatch.setenv("SK_GENERAL", which)
+    rng = np.random.default_rng(4242)
+    lens = [1, 2, 9, 10, 15, 16, 17, 19, 20, 31, 100, 159, 160, 161, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 4096, 5000,
+            10_240, 10_250, 16_384, 16_385, 16_399, 20_480, 30_000, 30_720, 69_999]
+    lens = np.array(lens + list(rng.integers(1, 12_000, size=96)), dtype=np.uint32)
+    rng.shuffle(lens)
+    n = len(lens)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    tot = int(offs[-1])
+    qual = np.clip(rng.normal(62, 6, tot).astype(int), 33, 74).astype(np.uint8)
+    for i in range(n):
+        a, b = int(offs[i]), int(offs[i + 1])
+        mode = i % 5
+        if mode == 0:    # bad start, good rest: the 5' cut moves in
+            qual[a:a + (b - a) // 3] = np.clip(rng.normal(40, 4, (b - a) // 3).astype(int), 33, 74)
+        elif mode == 1:  # collapse somewhere: the 3' cut
+            c = a + int(rng.integers(0, b - a))
+            qual[c:b] = np.clip(rng.normal(40, 4, b - c).astype(int), 33, 74)
+        elif mode == 2:  # collapse only in the last few bases: the windows after the last aligned one
+            c = max(a, b - int(rng.integers(1, 40)))
+            qual[c:b] = 35
+        elif mode == 3:  # hovering at the threshold
+            qual[a:b] = 53 + rng.integers(-1, 2, size=b - a)
+    seq = rng.choice(np.frombuffer(b"ACGT" * 400 + b"Nn", dtype=np.uint8), size=tot)
+    for q, l, x, tn in ((20, 20, 0, 0), (20, 0, 1, 0), (22, 100, 0, 1)):
+        p, po = both_params("sanger", q, l, x, tn)
+        want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=4)
+        assert err is None
+        got = sk_ctx.trim_batch(p, qual, seq, offsets=offs)  # sk_submit: host offsets
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, ("submit", q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+        import torch
+        dq, ds, do = (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda() for v in (qual, seq, offs))
+        out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+        for hint in (0, 70_000, 2000):  # left-overs behind the tile kernel / all reads by the general kernel / a hint too small
+            out.fill_(-7)
+            sk_ctx.scan_device_async(p, dq.data_ptr(), out.data_ptr(), n, offsets_ptr=do.data_ptr(), stride=hint,
+                                     seq_ptr=ds.data_ptr() if tn else None)
+            sk_ctx.scan_device_finish()
+            got = out.cpu().numpy()
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert bad.size == 0, ("device", hint, q, l, x, tn, bad[:5], got[bad[:5]], want[bad[:5]], lens[bad[:5]])
+    # a char out of range: reported iff the reference would have read it (before the 3' break + window), lowest read first
+    p, po = both_params("sanger", 20, 20, 0, 0)
+    for trial in range(12):
+        q2 = qual.copy()
+        r = int(rng.integers(0, n))
+        pos = int(offs[r]) + int(rng.integers(0, lens[r]))
+        q2[pos] = rng.choice([10, 32, 127, 200])
+        want, err = ob.oracle_trim_batch(po, q2, seq, offsets=offs, threads=1)
+        try:
+            got = sk_ctx.trim_batch(p, q2, seq, offsets=offs)
+            assert err is None, (trial, r, err, "device missed the error")
+            assert (got == want).all()
+        except capi.RangeError as e:
+            assert err is not None and (e.read, e.pos, e.ch) == tuple(err), (trial, r, err, (e.read, e.pos, e.ch))
+    # uniform fixed-stride batches (all reads, equal numbers of reads per wave)
+    for L in (1024, 3000, 8192, 12_345):
+        m = 50
+        qm = np.clip(rng.normal(58, 8, size=(m, L)).astype(int), 33, 74).astype(np.uint8)
+        qm[:, L - L // 4:] = 36
+        want, _ = ob.oracle_trim_batch(po, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
+        got = sk_ctx.trim_batch(p, qm.reshape(-1), stride=L, read_len=L, n_reads=m)
+        assert (got == want).all(), L
 
 
 @pytest.mark.parametrize("layout", ["tile", "wave_ragged", "wave_stride"])
