@@ -36,13 +36,6 @@
 // ------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ int sfirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t sfirst64(uint64_t v)
-{
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-
 // inclusive prefix sum over the wave, six DPP adds: within the rows, then lane 15 of row 0 / 2 into rows 1 / 3,
 // then lane 31 into rows 2 and 3
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
@@ -53,6 +46,23 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31
+    return v;
+}
+
+// offsets[r], offsets[r + 1] / lengths[r] for a wave-uniform r through the scalar cache.  The compiler takes
+// vector loads for them (it cannot prove the arrays unwritten in a kernel that stores), and those would sit in
+// the vector-memory counter between the blocks in flight: every read boundary would drain the loader.
+__device__ __forceinline__ void scalar_load_pair(const uint64_t *p, uint64_t &x, uint64_t &y)
+{
+    sk_v4u v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    x = ((uint64_t)v[1] << 32) | v[0];
+    y = ((uint64_t)v[3] << 32) | v[2];
+}
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t *p)
+{
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
 
@@ -106,14 +116,12 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
     auto locate = [&](uint64_t r, uint64_t &o, int &L) { // wave-uniform
         uint64_t e;
         if (offsets) {
-            o = offsets[r];
-            e = offsets[r + 1];
+            scalar_load_pair(offsets + r, o, e);
         } else {
             o = r * a.stride;
-            e = o + (lengths ? min(lengths[r], a.stride) : a.read_len);
+            e = o + (lengths ? min(scalar_load(lengths + r), a.stride) : a.read_len);
         }
-        o = sfirst64(o);
-        L = sfirst(e >= o ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0);
+        L = e >= o ? (int)min(e - o, (uint64_t)SK_MAX_READ_LEN_DEV) : 0;
     };
     auto window_of = [](int L) { const int w = L / 10; return w ? w : L; }; // trim.cpp:8, :30
     auto streamed = [&](int L) { return L > 0 && L >= a.lthr && window_of(L) <= maxw; };
@@ -349,7 +357,23 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                 if (phase < 2) {
                     const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
                     bool event = true;
-                    if (phase == 1 && (uint32_t)(j - jf0) < nfast) {
+                    const bool full = 1024 * (j + 1) <= L; // no lane's chunk reaches past the read
+                    if (full && 64 * (j + 1) <= wq) {
+                        // ---- a block before the end of the first window: range check, sums, prefix table
+                        uint32_t sad = 0, sum = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            sad = __builtin_amdgcn_sad_u8(d[u], min4, sad);
+                            sad = __builtin_amdgcn_sad_u8(d[u], max4, sad);
+                            sum = __builtin_amdgcn_sad_u8(d[u], 0u, sum);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(sad != clean) == 0) {
+                            const uint32_t incl = wave_scan_add(sum);
+                            *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = carry + incl - sum;
+                            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            event = false;
+                        }
+                    } else if (phase == 1 && (uint32_t)(j - jf0) < nfast) {
                         // ---- the usual block: inside the read, past the first window, looking for the first S < T.
                         // Nothing happens in it if every aligned window and its predecessor are 8 (qmax - qmin)
                         // or more above the threshold and every char is in range.
@@ -378,13 +402,22 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                     if (event) {
                         const int k = 64 * j + lane, x = 16 * k;
                         uint32_t sad = 0, sum = 0;
+                        if (full) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int n = L - x - 4 * u;
-                            const uint32_t xq = first_bytes(d[u], n, min4);
-                            sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
-                            sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
-                            sum = __builtin_amdgcn_sad_u8(first_bytes(d[u], n, 0u), 0u, sum);
+                            for (int u = 0; u < 4; ++u) {
+                                sad = __builtin_amdgcn_sad_u8(d[u], min4, sad);
+                                sad = __builtin_amdgcn_sad_u8(d[u], max4, sad);
+                                sum = __builtin_amdgcn_sad_u8(d[u], 0u, sum);
+                            }
+                        } else { // the read ends in this block
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int n = L - x - 4 * u;
+                                const uint32_t xq = first_bytes(d[u], n, min4);
+                                sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+                                sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+                                sum = __builtin_amdgcn_sad_u8(first_bytes(d[u], n, 0u), 0u, sum);
+                            }
                         }
                         const bool bad = sad != clean; // fillers are legal chars
                         const uint32_t incl = wave_scan_add(sum);

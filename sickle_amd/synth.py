@@ -52,6 +52,35 @@ def make_ragged_reads(seed, n, lo, hi, qualtype="illumina", n_frac=0.003, lower_
     return seq_m[mask], qual_m[mask], offsets
 
 
+def make_long_reads(seed, n, lo, hi):
+    """Long reads (Sanger chars), lengths log-uniform in lo..hi, of good quality with, read by read, a bad start,
+    a collapse somewhere, a collapse in the last bases only, a stretch hovering at Q20, or none of these;
+    an N or n in one read of three.  -> (seq_bytes, qual_bytes, offsets[n+1] uint64), packed back to back."""
+    rng = np.random.default_rng(seed)
+    lens = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n)).astype(np.int64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    tot = int(offsets[-1])
+    qual = np.clip(rng.normal(63, 5, tot).astype(int), 33, 74).astype(np.uint8)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=tot)
+    for i in range(n):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        mode = i % 5
+        if mode == 0:
+            qual[a:a + (b - a) // 4] = np.clip(rng.normal(41, 4, (b - a) // 4).astype(int), 33, 74)
+        elif mode == 1:
+            c = a + int(rng.integers(0, b - a))
+            qual[c:b] = np.clip(rng.normal(41, 4, b - c).astype(int), 33, 74)
+        elif mode == 2:
+            qual[max(a, b - int(rng.integers(1, 60))):b] = 35
+        elif mode == 3:
+            c = a + int(rng.integers(0, b - a))
+            qual[c:b] = 53 + rng.integers(-2, 3, size=b - c)
+        if i % 3 == 0:
+            seq[a + int(rng.integers(0, b - a))] = ord("N") if i % 2 else ord("n")
+    return seq, qual, offsets
+
+
 def pack_fixed(mat, stride):
     """Pad an (n, L) byte matrix to rows of `stride` bytes (zero fill) and flatten."""
     n, length = mat.shape

@@ -59,6 +59,20 @@ def prepare_inputs(tmp):
         assert md5_file(os.path.join(tmp, name)) == m, "synthetic input %s drifted from the golden run" % name
 
 
+def prepare_long_inputs(tmp):
+    """The long-read file of make_golden.py's write_long_inputs (same seeds -> same bytes)."""
+    tmp = str(tmp)
+    sa, qa, oa = synth.make_long_reads(909, 240, 1, 40_000)
+    sb, qb, obb = synth.make_ragged_reads(910, 60, 20, 400, "sanger")
+    recs = parse_fastq(synth.fastq_bytes_ragged(sa, qa, oa, prefix="LONG:"))
+    short = parse_fastq(synth.fastq_bytes_ragged(sb, qb, obb, prefix="SHORT:"))
+    for i, r in enumerate(short):
+        recs.insert(5 * i + 4, r)
+    open(os.path.join(tmp, "syn_long_inter.fastq"), "wb").write(b"".join(b"\n".join(r) + b"\n" for r in recs))
+    for name, m in e2e()["long_inputs_md5"].items():
+        assert md5_file(os.path.join(tmp, name)) == m, "synthetic input %s drifted from the golden run" % name
+
+
 def run_cli(binary, tmp, argv, env=None):
     real = [a.format(tmp=str(tmp), inputs=INPUTS) for a in argv]
     e = dict(os.environ)

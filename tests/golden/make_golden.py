@@ -182,6 +182,42 @@ def write_synth_inputs(tmp):
     return made
 
 
+def write_long_inputs(tmp):
+    """Long reads (1 .. 40 kb, the mates of a pair of different lengths, a few short ones between them),
+    interleaved; regenerated identically by tests/cli_util.py (md5 recorded)."""
+    sa, qa, oa = synth.make_long_reads(909, 240, 1, 40_000)
+    sb, qb, obb = synth.make_ragged_reads(910, 60, 20, 400, "sanger")
+    recs = parse_fastq(synth.fastq_bytes_ragged(sa, qa, oa, prefix="LONG:"))
+    short = parse_fastq(synth.fastq_bytes_ragged(sb, qb, obb, prefix="SHORT:"))
+    for i, r in enumerate(short):  # a short read after every fourth long one
+        recs.insert(5 * i + 4, r)
+    assert len(recs) % 2 == 0
+    data = b"".join(b"\n".join(r) + b"\n" for r in recs)
+    open(os.path.join(tmp, "syn_long_inter.fastq"), "wb").write(data)
+    return {"syn_long_inter.fastq": md5(os.path.join(tmp, "syn_long_inter.fastq"))}
+
+
+def long_reads_goldens(tmp):
+    """`sickle pe -c` of the reference on the long-read file: the general (streaming) kernel behind the CLI."""
+    inter = lambda extra: (["pe", "-c", "{tmp}/syn_long_inter.fastq", "-m", "{tmp}/om.fastq", "-a", "1", "-s", "{tmp}/os.fastq"] + extra,  # noqa: E731
+                           ["om.fastq", "os.fastq"])
+    runs = {
+        "pe_long_inter_sanger": inter(["-t", "sanger"]),
+        "pe_long_inter_sanger_n_q25": inter(["-t", "sanger", "-n", "-q", "25"]),
+        "pe_long_inter_sanger_x_l2000": inter(["-t", "sanger", "-x", "-l", "2000"]),
+    }
+    out = {}
+    for name, (argv, outputs) in runs.items():
+        for o in outputs:
+            if os.path.exists(os.path.join(tmp, o)):
+                os.remove(os.path.join(tmp, o))
+        rec = run_ref_pe(tmp, argv, outputs)
+        assert rec["rc"] == 0, (name, rec["stderr"][-300:])
+        out[name] = rec
+        print(name, {k: v["size"] for k, v in rec["outputs"].items()})
+    return out
+
+
 THREAD_ORDER_RUNS = {
     # name: (kind, inputs, qualtype, extra flags, threads)
     "pe_fr_illumina_a4": ("two", ("{inputs}/test.f.fastq", "{inputs}/test.r.fastq"), "illumina", [], 4),
@@ -254,6 +290,14 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             assert write_synth_inputs(tmp) == e2e["synth_inputs_md5"]
             e2e["thread_order"] = thread_order_goldens(tmp)
+        json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+        return
+    if "--only-long-reads" in sys.argv:  # adds / refreshes e2e.json["long_reads"], leaves the rest alone
+        assert ob.have_ref()
+        e2e = json.load(open(os.path.join(HERE, "e2e.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            e2e["long_inputs_md5"] = write_long_inputs(tmp)
+            e2e["long_reads"] = long_reads_goldens(tmp)
         json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
         return
     assert ob.have_ref(), "build oracle/_ref first (make -C oracle) in the container with /root/reference"
@@ -335,6 +379,8 @@ def main():
             e2e["runs"][name] = run_ref_pe(tmp, argv, outs)
             print(name, "rc", e2e["runs"][name]["rc"], {k: v["size"] for k, v in e2e["runs"][name]["outputs"].items()})
         e2e["thread_order"] = thread_order_goldens(tmp)
+        e2e["long_inputs_md5"] = write_long_inputs(tmp)
+        e2e["long_reads"] = long_reads_goldens(tmp)
         json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
 
 

@@ -36,6 +36,16 @@ def test_reference_runs_in_pieces_on_gpu(workdir, name):
     cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_SUBBATCH_READS": "7"})
 
 
+@pytest.mark.parametrize("general", ["default", "team", "stream"])
+@pytest.mark.parametrize("name", sorted(cu.e2e()["long_reads"].keys()))
+def test_long_reads_byte_identical_on_gpu(workdir, name, general):
+    """Reads of 1 .. 40 kb with short ones between them: ragged batches through sk_submit, the general kernels
+    (both forced in turn) behind the CLI, against the reference's files."""
+    cu.prepare_long_inputs(workdir)
+    cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["long_reads"][name],
+                 env=None if general == "default" else {"SK_GENERAL": general})
+
+
 def test_se_on_gpu_equals_selfpaired_reference(workdir):
     rec = cu.e2e()["runs"]["se_equiv_selfpair_illumina"]
     out = os.path.join(str(workdir), "se_self.fastq")

@@ -39,6 +39,13 @@ def test_reference_runs_in_pieces(hostcheck, workdir, name, piece):
     cu.check_run(hostcheck, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_SUBBATCH_READS": str(piece)})
 
 
+@pytest.mark.parametrize("name", sorted(cu.e2e()["long_reads"].keys()))
+def test_long_reads_byte_identical(hostcheck, workdir, name):
+    """Reads of 1 .. 40 kb with short ones between them (a ragged batch behind the CLI): the reference's files."""
+    cu.prepare_long_inputs(workdir)
+    cu.check_run(hostcheck, workdir, name, cu.e2e()["long_reads"][name])
+
+
 def se_expected(path, qt, q=20, l=20, no5=False, trunc_n=False, threads=1, batch_lines=None):
     """SE expectation = the oracle's cuts + the record format (`sickle se` itself crashes in the
     reference).  With threads > 1 the per-batch queue-major order is applied by the test."""
