@@ -285,8 +285,8 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             }
             // blocks [jf0, jf1): every lane's aligned window exists, has one before it, and ends inside the read
             const int jf0 = (wq + 64) >> 6, jf1 = (L - 15) >> 10;
-            const uint32_t nfast = (uint32_t)max(0, jf1 - jf0);
-            const int jtail = (((nwin - 1) >> 4) + wq) >> 6; // the block the last aligned window ends in
+            const int jtail = (((nwin - 1) >> 4) + wq) >> 6; // the block the last aligned window ends in: not one of them
+            const uint32_t nfast = (uint32_t)max(0, min(jf1, jtail) - jf0);
             int phase = a.no5 ? 1 : 0; // 0: looking for the first S >= T (trim.cpp:42), 1: for the first S < T after it (:61), 2: done
             int i0 = INF, i1 = INF, five = 0, three = L;
             uint32_t carry = 0; // sum of the read's bytes before the block
@@ -351,9 +351,62 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                 }
             };
 
+            bool have_block = false; // the block to scan has arrived already (the lockstep run below stopped at it)
 #pragma unroll 1
             for (j = 0; j < nbq; ++j, k4 += 256u) {
-                arrive();
+                if (phase == 1 && pact && !pslow && ahead == DEPTH && (uint32_t)(j - jf0) < nfast) {
+                    // ---- lockstep run: the scan is in the usual blocks of its read (see below) and the loader in the
+                    // middle of a stream, DEPTH blocks ahead.  One load, one counted wait, one block scanned per
+                    // turn, nothing else: what the general turn below decides per block is decided once here.
+                    // The scalar unit is the bottleneck of this kernel (one per CU, shared by all its waves).
+                    const int nrun = min((int)(jf0 + nfast) - j, pleft - 1);
+                    int done = 0;
+                    bool ev = false;
+                    while (done < nrun) {
+                        if (prem > 0) __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)(lds + pbase), 16, 0, SK_DMA_AUX);
+                        psrc += 1024;
+                        prem -= 1024;
+                        pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
+                        wait_vmcnt_imm<DEPTH>();
+                        const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
+                        uint32_t sad = 0, sum = 0, part = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            sad = __builtin_amdgcn_sad_u8(d[u], min4, sad);
+                            sad = __builtin_amdgcn_sad_u8(d[u], max4, sad);
+                            sum = __builtin_amdgcn_sad_u8(d[u], 0u, sum);
+                            part = __builtin_amdgcn_sad_u8(d[u] & pm[u], 0u, part);
+                        }
+                        const uint32_t incl = wave_scan_add(sum);
+                        const uint32_t P = carry + incl - sum;
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = P;
+                        const uint32_t Pa = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table) + ((k4 - wq4) & tmask4));
+                        const int v = (int)(P + part - Pa) - T;
+                        const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false); // wave_shr:1
+                        const bool quiet = min(v, vp) >= B8 && sad == clean;
+                        if (__builtin_amdgcn_ballot_w64(!quiet)) {
+                            ev = true;
+                            break;
+                        }
+                        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        vprev = __builtin_amdgcn_readlane(v, 63);
+                        cbase = cbase + 1024u == ring_bytes ? 0u : cbase + 1024u;
+                        k4 += 256u;
+                        ++done;
+                    }
+                    pleft -= done + (ev ? 1 : 0);
+                    j += done;
+                    if (ev) {
+                        ahead = DEPTH + 1;
+                        have_block = true;
+                    }
+                }
+                if (have_block) {
+                    --ahead;
+                    have_block = false;
+                } else {
+                    arrive();
+                }
                 if (phase < 2) {
                     const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
                     bool event = true;
@@ -395,7 +448,6 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                         if (__builtin_amdgcn_ballot_w64(!quiet) == 0) {
                             carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                             vprev = __builtin_amdgcn_readlane(v, 63);
-                            if (j == jtail) vtail = __builtin_amdgcn_readlane(v, (((nwin - 1) >> 4) + wq) & 63);
                             event = false;
                         }
                     }
