@@ -314,37 +314,33 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             };
             // One cell: the windows base + 1 .. base + cnt given Sb = S_base - T (cnt == 0: window 0 alone, Sb its
             // S - T), trim.cpp:34-81 over them in order
-            auto cell = [&](int base, int Sb, int cnt) {
-                uint32_t ge, vm;
+            auto cell = [&](int base, int Sb, int cnt) { // cnt <= 64: up to four cells in one go, a window per lane
+                uint64_t ge, vm;
                 if (cnt == 0) {
                     ge = Sb >= 0 ? 1u : 0u;
                     vm = 1u;
                 } else {
-                    const int u = lane & 15;
                     int dl = 0;
-                    if (u < cnt) dl = ringbyte(base + w + u) - ringbyte(base + u); // trim.cpp:76-80
-                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x111, 0xf, 0xf, true); // inclusive scan over the row
-                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x112, 0xf, 0xf, true);
-                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x114, 0xf, 0xf, true);
-                    dl += __builtin_amdgcn_update_dpp(0, dl, 0x118, 0xf, 0xf, true);
-                    ge = (uint32_t)__builtin_amdgcn_ballot_w64(Sb + dl >= 0) & 0xffffu; // bit u: S_{base + 1 + u} >= T
-                    vm = (1u << cnt) - 1u;
+                    if (lane < cnt) dl = ringbyte(base + w + lane) - ringbyte(base + lane); // trim.cpp:76-80
+                    dl = (int)wave_scan_add((uint32_t)dl);
+                    ge = __builtin_amdgcn_ballot_w64(Sb + dl >= 0); // bit u: S_{base + 1 + u} >= T
+                    vm = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
                 }
-                uint32_t lt = ~ge & vm;
+                uint64_t lt = ~ge & vm;
                 if (phase == 0) {
                     lt = 0;
-                    const uint32_t g = ge & vm;
+                    const uint64_t g = ge & vm;
                     if (g) {
-                        const int u0 = __builtin_ctz(g);
+                        const int u0 = __builtin_ctzll(g);
                         i0 = base + 1 + u0;
                         phase = 1;
-                        lt = ~ge & vm & ~((2u << u0) - 1u);
+                        lt = ~ge & vm & ~((2ull << u0) - 1ull);
                         five = first_char(i0, true); // trim.cpp:46-51
                         if (five == INF) five = 0;
                     }
                 }
                 if (phase == 1 && lt) {
-                    i1 = base + 1 + __builtin_ctz(lt);
+                    i1 = base + 1 + __builtin_ctzll(lt);
                     phase = 2;
                     three = first_char(i1, false); // trim.cpp:65-70
                     if (three == INF) three = L;
@@ -512,9 +508,17 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                             if (!m) break;
                             const int t = __builtin_ctzll(m);
                             const int at = 64 * j + t - wq;
-                            if (at == 0) cell(-1, __builtin_amdgcn_readlane(v, t), 0);
-                            else cell(16 * (at - 1), __builtin_amdgcn_readlane(vp, t), 16);
-                            cur = t + 1;
+                            if (at == 0) {
+                                cell(-1, __builtin_amdgcn_readlane(v, t), 0);
+                                cur = t + 1;
+                            } else {
+                                // this cell and the next three: a crossing takes a few cells, and the lanes are there.
+                                // As far as the windows go, and their chars lie in this block.
+                                const int base = 16 * (at - 1);
+                                const int cnt = min(min(64, 16 * (64 - t)), nwin - 1 - base);
+                                cell(base, __builtin_amdgcn_readlane(vp, t), cnt);
+                                cur = t + ((cnt + 15) >> 4);
+                            }
                         }
                     }
                 }
