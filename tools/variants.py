@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-NAMES = ("n150", "u250", "u100", "seg", "seg_n", "seg_scatter", "packed150", "ragged150", "ragged_mix", "long")
+NAMES = ("n150", "u250", "u100", "seg", "seg_n", "seg_scatter", "packed150", "ragged150", "ragged_mix", "long", "long30k")
 
 
 def _quals(torch, shape, dev, seed):
@@ -77,6 +77,14 @@ def build(name, torch, capi, ctx, dev, stream, bench):
         return dict(uniform(150, 10_000_000, False), keep=keep)
     if name == "u100":
         return dict(uniform(100, 10_000_000, False), keep=keep)
+    if name == "long30k":  # uniform long reads back to back: the streaming general kernel without per-read variety
+        L, n = 30_000, 33_333
+        q = _quals(torch, (n * L,), dev, 35)  # (the 150 bp quality model decays to nothing within a kilobase)
+        out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        keep.extend([q, out])
+        return dict(launch=lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, stream=sp),
+                    n_reads=n, algo_bytes=n * (L + 8), kernel="sk_scan_stream_kernel",
+                    workload="30 kb reads back to back (stride 30000), %d reads: a wave per read, the read streamed through LDS" % n, keep=keep)
     if name == "packed150":
         d = uniform(150, 10_000_000, False, stride=150)
         d["workload"] = "150 bp reads packed back to back (stride 150): tiles re-strided into LDS, " + d["workload"]
