@@ -251,10 +251,21 @@ def test_empty_and_truncated_inputs(hostcheck, workdir):
             path = os.path.join(d, name)
             copy = os.path.join(d, "copy_" + name)
             open(copy, "wb").write(data)
-            pr = subprocess.run([ob.REF_BIN, "pe", "-f", path, "-r", copy, "-t", "sanger", "-o", path + ".r1", "-p",
-                                 path + ".r2", "-s", path + ".rs", "-a", "1"], capture_output=True, timeout=60)
-            assert pr.returncode == 0
-            assert open(path + ".r1", "rb").read() == open(os.path.join(d, name + ".out"), "rb").read(), name
+            # The reference's main thread does not wait for its last output thread (src/trim_paired.cpp:445-458):
+            # about one run in fifty leaves file 1 short.  A short file must be a prefix of ours; one complete run
+            # in six has to be there.
+            ours = open(os.path.join(d, name + ".out"), "rb").read()
+            complete = False
+            for attempt in range(6):
+                pr = subprocess.run([ob.REF_BIN, "pe", "-f", path, "-r", copy, "-t", "sanger", "-o", path + ".r1", "-p",
+                                     path + ".r2", "-s", path + ".rs", "-a", "1"], capture_output=True, timeout=60)
+                assert pr.returncode == 0
+                theirs = open(path + ".r1", "rb").read()
+                assert ours.startswith(theirs), (name, attempt, len(theirs), len(ours))
+                if theirs == ours:
+                    complete = True
+                    break
+            assert complete, name
 
 
 def test_output_to_a_pipe(hostcheck, workdir):
