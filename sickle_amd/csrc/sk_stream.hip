@@ -187,8 +187,11 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
         }
         // ---- the loader: a cursor over the blocks of the span, DEPTH ahead of the scan.  Per lane: where its
         // next chunk comes from and how many bytes of the read are left from there.
-        uint64_t pr = lo;
-        int pact = 1, pseek = 1;
+        // The read after the one being loaded is looked up one stream ahead (nstate: 0 not yet, 1 found, 2 none
+        // left), so that the change of streams is a handful of moves wherever it happens.
+        uint64_t pnext = lo, n_po = 0;
+        int n_pL = 0, nstate = 0;
+        int pact = 0;
         int pslow = 0; // the read's last chunk leaves the batch (careful loads), or its last block is empty
         int pk = 0, pleft = 0; // blocks left of the read's current stream (quality, then the sequence)
         uint64_t po = 0;
@@ -196,25 +199,43 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
         const uint8_t *psrc = nullptr;
         int prem = 0;
         int ahead = 0; // blocks issued and not yet scanned
-        auto issue = [&]() {
-            if (pseek) { // the first read at or after pr that goes through the ring
-                pseek = 0;
-                pact = 0;
-                while (pr < hi) {
-                    locate(pr, po, pL);
-                    if (streamed(pL)) {
-                        pk = 0;
-                        pleft = (pL >> 10) + 1; // chunk index L >> 4 included: the window that ends with the read may end there
-                        // that block is empty if L is a multiple of 1024; or the read's last chunk leaves the batch
-                        pslow = ((pL & 1023) == 0 || po + (((uint64_t)pL + 15u) & ~15ull) > batch_end) ? 1 : 0;
-                        psrc = qual + po + lane16;
-                        prem = pL - (int)lane16;
-                        pact = 1;
-                        break;
-                    }
-                    ++pr;
+        auto seek_next = [&]() { // the first read at or after pnext that goes through the ring
+            nstate = 2;
+            while (pnext < hi) {
+                locate(pnext, n_po, n_pL);
+                ++pnext;
+                if (streamed(n_pL)) {
+                    nstate = 1;
+                    break;
                 }
             }
+        };
+        auto next_stream = [&]() { // the current stream has been loaded to its end
+            if (HAS_SEQ && pk == 0 && pact) {
+                pk = 1;
+                pleft = (pL + 1023) >> 10;
+                psrc = seq + po + lane16;
+                prem = pL - (int)lane16;
+                return;
+            }
+            if (nstate == 0) seek_next();
+            pact = 0;
+            if (nstate == 1) {
+                po = n_po;
+                pL = n_pL;
+                nstate = 0;
+                pk = 0;
+                pleft = (pL >> 10) + 1; // chunk index L >> 4 included: the window that ends with the read may end there
+                // that block is empty if L is a multiple of 1024; or the read's last chunk leaves the batch
+                pslow = ((pL & 1023) == 0 || po + (((uint64_t)pL + 15u) & ~15ull) > batch_end) ? 1 : 0;
+                psrc = qual + po + lane16;
+                prem = pL - (int)lane16;
+                pact = 1;
+            }
+        };
+        next_stream();
+        auto issue = [&]() {
+            if (nstate == 0) seek_next();
             if (!pact) return;
             uint8_t *dst = lds + pbase;
             if (!pslow) {
@@ -232,17 +253,7 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
             psrc += 1024;
             prem -= 1024;
-            if (--pleft == 0) {
-                if (HAS_SEQ && pk == 0) {
-                    pk = 1;
-                    pleft = (pL + 1023) >> 10;
-                    psrc = seq + po + lane16;
-                    prem = pL - (int)lane16;
-                } else {
-                    ++pr;
-                    pseek = 1;
-                }
-            }
+            if (--pleft == 0) next_stream();
         };
         // the scan's block has arrived when every load but those issued after it has returned
         auto arrive = [&]() {
@@ -355,14 +366,18 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                     // middle of a stream, DEPTH blocks ahead.  One load, one counted wait, one block scanned per
                     // turn, nothing else: what the general turn below decides per block is decided once here.
                     // The scalar unit is the bottleneck of this kernel (one per CU, shared by all its waves).
-                    const int nrun = min((int)(jf0 + nfast) - j, pleft - 1);
+                    const int nrun = (int)(jf0 + nfast) - j;
                     int done = 0;
-                    bool ev = false;
-                    while (done < nrun) {
+                    bool ev = false, stop = false;
+                    while (done < nrun && !stop) {
                         if (prem > 0) __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)(lds + pbase), 16, 0, SK_DMA_AUX);
                         psrc += 1024;
                         prem -= 1024;
                         pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
+                        if (--pleft == 0) { // the loader goes on with the next stream, the scan stays in its read
+                            next_stream();
+                            stop = !pact || pslow;
+                        }
                         wait_vmcnt_imm<DEPTH>();
                         const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
                         uint32_t sad = 0, sum = 0, part = 0;
@@ -390,7 +405,6 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                         k4 += 256u;
                         ++done;
                     }
-                    pleft -= done + (ev ? 1 : 0);
                     j += done;
                     if (ev) {
                         ahead = DEPTH + 1;
