@@ -156,7 +156,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->team_rbuf = 0;
     a->team_maxlen = 0;
     a->stream_nb = 0;
-    a->span_reads = 0;
+    a->stream_read_cost = 0;
     a->stream_tbl = 0;
     return SK_OK;
 }

@@ -51,7 +51,7 @@ struct sk_scan_args {
     uint32_t team_rbuf;   // general kernel: LDS bytes of one read's buffer
     uint32_t team_maxlen; // general kernel: the longest read that goes through LDS
     uint32_t stream_nb;   // streaming general kernel: 1 KiB blocks in a wave's ring
-    uint32_t span_reads;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
+    uint32_t stream_read_cost;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
     uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
 };
 

@@ -127,7 +127,7 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
     auto streamed = [&](int L) { return L > 0 && L >= a.lthr && window_of(L) <= maxw; };
 
     // The spans.  All reads (a.buf_bytes == 0): ONE span per wave, the batch cut into gridDim.x runs of
-    // consecutive reads of equal cost -- bytes plus a.span_reads bytes per read, found by a search in `offsets`
+    // consecutive reads of equal cost -- bytes plus a.stream_read_cost bytes per read, found by a search in `offsets`
     // (a deal of reads by number leaves the slowest of 3 584 waves 45 % over the mean on a 1-30 kb mix); equal
     // numbers of reads without offsets.  Or (a.buf_bytes != 0) the runs of 8 reads of the 64-read tiles
     // sk_scan_tile_any_kernel left -- if it left any: it has put this scan's number into the word after the
@@ -142,7 +142,7 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             // cost(r) = offsets[r] - offsets[0] + c r, r in [0, n]: ascending.  The span of wave g starts at the
             // first r with cost(r) >= g total / G and ends where the next one starts.  Both bounds at once: the
             // lower half of the wave searches one, the upper half the other, 32 probes per round.
-            const uint64_t c = a.span_reads, base = offsets[0];
+            const uint64_t c = a.stream_read_cost, base = offsets[0];
             const uint64_t total = offsets[n] - base + c * n;
             const int half = lane >> 5, sub = lane & 31;
             const uint64_t tgt = (g + (uint64_t)half) * total / G; // total < 2^48, G < 2^16
@@ -613,7 +613,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
     // one span of consecutive reads per wave, cut at equal cost: a read counts as its bytes plus this many
     // (what a read costs beyond its blocks: the first window, the cut searches, the store)
     static const uint32_t read_cost = [] { const char *e = getenv("SK_STREAM_READ_COST"); return e ? (uint32_t)atoll(e) : 4096u; }();
-    at.span_reads = read_cost;
+    at.stream_read_cost = read_cost;
     const uint64_t n_units = a->buf_bytes ? (a->n_reads + 7) / 8 : a->n_reads;
     if (grid > n_units) grid = n_units;
     if (grid == 0) return hipSuccess;
