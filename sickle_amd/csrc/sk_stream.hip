@@ -11,9 +11,10 @@
 // consecutive reads and a ring of NB blocks of 1 KiB; block b of a read = its bytes [1024 b, 1024 b + 1024),
 // fetched by ONE LDS-DMA instruction (16 bytes per lane, the source address per lane: a read starts a block
 // wherever it lies in the batch).  The blocks of the span -- read after read, with -n a read's sequence
-// blocks after its quality blocks -- form one sequence; the DMA runs SK_STREAM_DEPTH blocks ahead of the
-// scan with counted waits (s_waitcnt vmcnt(n): loads return in order), across read boundaries, so the
-// pipeline only drains at the end of a span.  10 KiB of LDS per wave at 30 kb: 16 waves per CU.
+// blocks after its quality blocks -- form one sequence; the DMA runs DEPTH (3) blocks ahead of the scan with
+// counted waits (s_waitcnt vmcnt(n): loads return in order), across read boundaries, so the pipeline only
+// drains at the end of a span.  8 KiB of ring + 2 KiB of table per wave at 30 kb: 16 waves per CU.  A wave's
+// span: the batch cut at equal cost (bytes + a.stream_read_cost per read) by a search in `offsets`.
 //
 // The scan of a quality block (lane t holds chunk k = 64 b + t, the bytes [16 k, 16 k + 16)):
 //   1. range check (two v_sad_u8 per dword) and chunk sum; a wave prefix scan turns the sums into
@@ -24,8 +25,8 @@
 //      qmax - qmin each (chars in range; a char out of range among the bytes the reference reads is an
 //      error whatever the cut): if v_{a-1} and v_a lie on one side of 0 by 8 (qmax - qmin) or more, so do
 //      all windows between them.  Two ballots give the cells that may hold the first window at/above the
-//      threshold and the first one below it; only those are evaluated window by window (16 lanes, byte
-//      differences, a DPP row scan): normally two cells per read.
+//      threshold and the first one below it; only those are evaluated window by window -- the flagged cell and
+//      the three after it, a window per lane: byte differences, a wave scan, a ballot: once or twice per read.
 //   4. the read's state (looking for the first S >= T; for the first S < T after it; done) is wave-uniform
 //      and steps through the flagged cells in order; trim.cpp:46-51 and :65-70 (the first char at/above
 //      resp. below the threshold inside the window) read the ring 64 bytes at a time.
@@ -33,6 +34,10 @@
 // / 1024) blocks, sized by the launcher from the caller's longest-read hint; a read whose window does not
 // fit is scanned from global memory by the whole wave (scan_read_global: correctness path).
 // With a.buf_bytes != 0 the kernel takes only the 64-read tiles sk_scan_tile_any_kernel left.
+//
+// What bounds it is instruction issue, the scalar unit first (one per CU for all its waves): hence the
+// lockstep run in the block loop, the uniform constants kept in vector registers, and the loader that looks
+// one read ahead.  DESIGN.md 4.3 has the counters of each step.
 // ------------------------------------------------------------------------------------------
 namespace {
 
