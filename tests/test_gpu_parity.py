@@ -133,6 +133,17 @@ def test_both_general_kernels_on_every_length(sk_ctx, which, monkeypatch):
             assert (got == want).all()
         except capi.RangeError as e:
             assert err is not None and (e.read, e.pos, e.ch) == tuple(err), (trial, r, err, (e.read, e.pos, e.ch))
+        # the same through the device-resident entry points: all reads by the general kernel / left-overs of the tile kernel
+        dq2 = torch.from_numpy(q2).cuda()
+        for hint in (70_000, 0):
+            out.fill_(-7)
+            sk_ctx.scan_device_async(p, dq2.data_ptr(), out.data_ptr(), n, offsets_ptr=do.data_ptr(), stride=hint)
+            try:
+                sk_ctx.scan_device_finish()
+                assert err is None, (trial, hint, r, err, "device missed the error")
+                assert (out.cpu().numpy() == want).all()
+            except capi.RangeError as e:
+                assert err is not None and (e.read, e.pos, e.ch) == tuple(err), (trial, hint, err, (e.read, e.pos, e.ch))
     # uniform fixed-stride batches (all reads, equal numbers of reads per wave)
     for L in (1024, 3000, 8192, 12_345):
         m = 50
