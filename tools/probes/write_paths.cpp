@@ -4,7 +4,11 @@
 //   d) as c with MAP_POPULATE (pages made by the mapping call, one thread), then T threads memcpy
 //   e) three files, one pwrite stream each (what the CLI's writer stage does now)
 // usage: write_paths <dir> <GiB> <threads>
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <fcntl.h>
+#include <linux/falloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -103,6 +107,46 @@ int main(int argc, char **argv)
         report(nm, now() - t0);
         for (int i = 0; i < 3; ++i) close(fds[i]);
         unlink(path("f0").c_str()); unlink(path("f1").c_str()); unlink(path("f2").c_str());
+    }
+    {   // g) posix_fallocate of the whole file (pages made and zeroed, no data), then one / two pwrite streams into it
+        for (int streams : {1, 2}) {
+            int fd = fresh("g");
+            double t0 = now();
+            if (fallocate(fd, 0, 0, (off_t)bytes)) { perror("fallocate"); return 1; }
+            double t1 = now();
+            std::vector<std::thread> ts;
+            for (int i = 0; i < streams; ++i) ts.emplace_back([&, i] { pw_range(fd, bytes / streams * i, i == streams - 1 ? bytes : bytes / streams * (i + 1)); });
+            for (auto &t : ts) t.join();
+            double t2 = now();
+            char nm[160]; snprintf(nm, sizeof nm, "g) fallocate (%.3f s = %.2f GB/s) then %d pwrite stream(s) into the made pages (%.3f s = %.2f GB/s)", t1 - t0, bytes / (t1 - t0) / 1e9, streams, t2 - t1, bytes / (t2 - t1) / 1e9);
+            report(nm, now() - t0);
+            close(fd); unlink(path("g").c_str());
+        }
+    }
+    {   // h) two files: a helper thread fallocates 256 MiB ahead of each file's single pwrite stream
+        int fds[2] = {fresh("h0"), fresh("h1")};
+        const size_t per = bytes / 2, step = 256u << 20;
+        double t0 = now();
+        std::vector<std::thread> ts;
+        for (int f = 0; f < 2; ++f) {
+            ts.emplace_back([&, f] { for (size_t at = 0; at < per; at += step) if (fallocate(fds[f], FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)std::min(step, per - at))) { perror("fallocate"); exit(1); } });
+            ts.emplace_back([&, f] { pw_range(fds[f], 0, per); });
+        }
+        for (auto &t : ts) t.join();
+        report("h) two files, each: one thread fallocating ahead + one pwrite stream (half of the bytes each)", now() - t0);
+        for (int f = 0; f < 2; ++f) close(fds[f]);
+        unlink(path("h0").c_str()); unlink(path("h1").c_str());
+    }
+    {   // i) two files, one pwrite stream each, nothing else (the reference point for h)
+        int fds[2] = {fresh("i0"), fresh("i1")};
+        const size_t per = bytes / 2;
+        double t0 = now();
+        std::vector<std::thread> ts;
+        for (int f = 0; f < 2; ++f) ts.emplace_back([&, f] { pw_range(fds[f], 0, per); });
+        for (auto &t : ts) t.join();
+        report("i) two files, one pwrite stream each (half of the bytes each)", now() - t0);
+        for (int f = 0; f < 2; ++f) close(fds[f]);
+        unlink(path("i0").c_str()); unlink(path("i1").c_str());
     }
     return 0;
 }
