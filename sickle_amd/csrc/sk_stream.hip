@@ -309,6 +309,7 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             int vprev = 0, vtail = 0;
             int pb = INF, pbch = 0; // first char out of range
             int j = 0;              // the block being scanned
+            bool tail_seen = false; // the windows after the last aligned one were part of a cell already
             uint32_t k4 = 4u * (uint32_t)lane; // 4 * this lane's chunk number
 
             // byte at read position p, which lies in block j or up to NB - DEPTH - 1 blocks before it
@@ -537,6 +538,9 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                                 const int cnt = min(min(64, 16 * (64 - t)), nwin - 1 - base);
                                 cell(base, __builtin_amdgcn_readlane(vp, t), cnt);
                                 cur = t + ((cnt + 15) >> 4);
+                                // (it ends on a multiple of 16, or with the read's last window: then the windows
+                                // after the last aligned one have had their turn)
+                                tail_seen = tail_seen || base + cnt == nwin - 1;
                             }
                         }
                     }
@@ -544,7 +548,7 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                 if (j + 1 < nbq) leave();
             }
             j = nbq - 1;
-            if (phase < 2) { // the windows after the last aligned one
+            if (phase < 2 && !tail_seen) { // the windows after the last aligned one
                 const int alast = (nwin - 1) >> 4, rem = nwin - 1 - 16 * alast;
                 if (rem > 0) {
                     const bool none = phase == 0 ? vtail < -rem * range : vtail >= rem * range;
