@@ -677,6 +677,36 @@ def test_random_fuzz_medium_and_long_reads(sk_ctx):
             assert (got == want).all(), ("uniform", trial, L)
 
 
+def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
+    """(1) The read that a soak run caught: 137 bases, bad until the last 14 -- the first window at the threshold is
+    one of those after the last aligned one, which a 64-window cell of the streaming kernel had already run through
+    when the tail step looked at them again (phase "looking for the first S < T") and cut at a window BEFORE the 5'
+    one.  Next to a read long enough to send the batch to the general kernels.  (2) tools/probes/soak_general.py,
+    300 random batches: every encoding, thresholds 0..41, -l, -x, -n, lengths 1..200 kb, chars out of range, both
+    general kernels forced in turn, sk_submit and the device entry points with and without hints."""
+    h = ("2f2d322f2d2c2c32312d312d322e2e302e31302f31322e2c2e322d2d2f322c312d2f2d2e302d2c2c2f32322f2f3230312c312e2c2d2e2c2f"
+         "3130302f2d2c2d3030322d2c2e2e2c2d2c32302e32322d2f322e2f2e2f2e2e2f302e2c2f3130322d312e302f2c2d312c302f31302c2d3032"
+         "2c2d312e322e2d322e30305b5a5f5c5d5f5c5a5f5e5c5e5a59")
+    r = np.frombuffer(bytes.fromhex(h), dtype=np.uint8)
+    p, po = both_params("sanger", 30, 0, 0, 0)
+    for which in ("team", "stream"):
+        monkeypatch.setenv("SK_GENERAL", which)
+        for before, after in (([], [2387]), ([53, 103], [2387, 1]), ([1500], []), ([100] * 4, [100, 100, 5000])):
+            parts = [np.full(l, 45, dtype=np.uint8) for l in before] + [r] + [np.full(l, 70, dtype=np.uint8) for l in after]
+            offs = np.zeros(len(parts) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(x) for x in parts])
+            q = np.concatenate(parts)
+            want, _ = ob.oracle_trim_batch(po, q, None, offsets=offs, threads=1)
+            assert list(want[len(before)]) == [123, 137]
+            got = sk_ctx.trim_batch(p, q, None, offsets=offs)
+            assert (got == want).all(), (which, before, after, got, want)
+    monkeypatch.delenv("SK_GENERAL")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools", "probes"))
+    import soak_general
+    assert soak_general.run(300, 2026, verbose=False) == 300 * 8
+
+
 def test_segmented_long_rows_and_partial_tiles(sk_ctx):
     """Segmented batches without -n, rows up to 312 bytes (8 waves per CU), length groups of every size (1 read ...
     several full tiles + a partial one) so that full and partial tiles alternate in every order; cuts in read order
