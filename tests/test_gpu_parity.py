@@ -707,6 +707,17 @@ def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
     assert soak_general.run(300, 2026, verbose=False) == 300 * 8
 
 
+def test_tile_kernels_soak(sk_ctx):
+    """tools/probes/soak_tiles.py, 400 random short-read batches through every layout of the lane-per-read kernels
+    (fixed stride with an odd / even number of 8-byte units, packed, unaligned, with per-read lengths; ragged;
+    segmented in read order and in slot order), every encoding, thresholds 0..41, -l, -x, -n, chars out of range.
+    (18 000 such batches ran clean when the soak was written.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools", "probes"))
+    import soak_tiles
+    assert soak_tiles.run(400, 2027, verbose=False) > 400 * 5
+
+
 def test_segmented_long_rows_and_partial_tiles(sk_ctx):
     """Segmented batches without -n, rows up to 312 bytes (8 waves per CU), length groups of every size (1 read ...
     several full tiles + a partial one) so that full and partial tiles alternate in every order; cuts in read order
