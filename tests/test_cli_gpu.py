@@ -46,6 +46,19 @@ def test_long_reads_byte_identical_on_gpu(workdir, name, general):
                  env=None if general == "default" else {"SK_GENERAL": general})
 
 
+def test_cli_soak_against_reference_on_gpu():
+    """tools/probes/soak_cli.py with the product binary: 40 random paired inputs against the chunks derived from the
+    oracle and against the compiled reference (which travels to the box as oracle/_ref)."""
+    import sys
+    import oracle_bind as ob
+    if not ob.have_ref():
+        pytest.skip("needs the compiled reference (oracle/_ref)")
+    sys.path.insert(0, os.path.join(cu.ROOT, "tools", "probes"))
+    import soak_cli
+    soak_cli.NEW = cu.PRODUCT_BIN
+    assert soak_cli.run(40, 505, verbose=False) == 40
+
+
 def test_se_on_gpu_equals_selfpaired_reference(workdir):
     rec = cu.e2e()["runs"]["se_equiv_selfpair_illumina"]
     out = os.path.join(str(workdir), "se_self.fastq")

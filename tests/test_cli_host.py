@@ -46,6 +46,18 @@ def test_long_reads_byte_identical(hostcheck, workdir, name):
     cu.check_run(hostcheck, workdir, name, cu.e2e()["long_reads"][name])
 
 
+@pytest.mark.skipif(not ob.have_ref(), reason="needs the compiled reference (oracle/_ref)")
+def test_cli_soak_against_reference(hostcheck):
+    """tools/probes/soak_cli.py, 80 random paired inputs (two files / interleaved; equal, mixed, long and tiny reads;
+    every encoding; -q -l -x -n): this CLI writes the per-batch chunks derived from the oracle in batch order, the
+    compiled reference a permutation of exactly those chunks, the summaries agree."""
+    import sys
+    sys.path.insert(0, os.path.join(cu.ROOT, "tools", "probes"))
+    import soak_cli
+    soak_cli.NEW = hostcheck
+    assert soak_cli.run(80, 404, verbose=False) == 80
+
+
 def se_expected(path, qt, q=20, l=20, no5=False, trunc_n=False, threads=1, batch_lines=None):
     """SE expectation = the oracle's cuts + the record format (`sickle se` itself crashes in the
     reference).  With threads > 1 the per-batch queue-major order is applied by the test."""
