@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import cli_util as cu
 import oracle_bind as ob
-from fastq_util import (expected_pe_outputs, file_lines, is_permutation_of_chunks, pack_records, parse_fastq, reference_batch_len,
+from fastq_util import (expected_pe_outputs, expected_se_output, file_lines, is_permutation_of_chunks, pack_records, parse_fastq, reference_batch_len,
                         reference_batches)
 
 NEW = os.path.join(ROOT, "sickle_amd", "sickle")
@@ -67,6 +67,7 @@ def run(iters=20, seed=1, verbose=True):
             r1 = records(rng, n, l1, lo, hi, mid, b"r", 1)
             r2 = records(rng, n, l2, lo, hi, mid, b"r", 2)
             flags = ["-t", qt, "-q", str(thr), "-l", str(int(rng.choice([0, 20, 50])))]
+            T = int(rng.choice([1, 1, 1, 2, 3, 7, 16]))  # -a T: the queue-major order inside every batch
             if rng.integers(0, 2):
                 flags.append("-x")
             if rng.integers(0, 2):
@@ -74,13 +75,13 @@ def run(iters=20, seed=1, verbose=True):
             if inter:
                 open(os.path.join(d, "c.fastq"), "wb").write(b"".join(a + b for a, b in zip(r1, r2)))
                 outs = ["om", "os"]
-                argv = lambda pre: ["pe", "-c", os.path.join(d, "c.fastq"), "-m", os.path.join(d, pre + "om"), "-s", os.path.join(d, pre + "os"), "-a", "1"] + flags  # noqa: E731
+                argv = lambda pre: ["pe", "-c", os.path.join(d, "c.fastq"), "-m", os.path.join(d, pre + "om"), "-s", os.path.join(d, pre + "os"), "-a", str(T)] + flags  # noqa: E731
             else:
                 open(os.path.join(d, "f.fastq"), "wb").write(b"".join(r1))
                 open(os.path.join(d, "r.fastq"), "wb").write(b"".join(r2))
                 outs = ["o1", "o2", "os"]
                 argv = lambda pre: ["pe", "-f", os.path.join(d, "f.fastq"), "-r", os.path.join(d, "r.fastq"), "-o", os.path.join(d, pre + "o1"),  # noqa: E731
-                                    "-p", os.path.join(d, pre + "o2"), "-s", os.path.join(d, pre + "os"), "-a", "1"] + flags
+                                    "-p", os.path.join(d, pre + "o2"), "-s", os.path.join(d, pre + "os"), "-a", str(T)] + flags
             # the expectation: per ingest batch, what `pe -a 1` writes for it
             paths = [os.path.join(d, "c.fastq")] if inter else [os.path.join(d, "f.fastq"), os.path.join(d, "r.fastq")]
             datas = [open(q, "rb").read() for q in paths]
@@ -94,7 +95,7 @@ def run(iters=20, seed=1, verbose=True):
             blen = reference_batch_len(len(datas[0]), 512, paired=True)
             b1 = reference_batches(file_lines(datas[0]), blen, 8 if inter else 4)
             b2 = None if inter else reference_batches(file_lines(datas[1]), blen, 4)
-            chunks = expected_pe_outputs(b1, b2, lambda f, r: cuts[f][r], 1, interleaved=inter)
+            chunks = expected_pe_outputs(b1, b2, lambda f, r: cuts[f][r], T, interleaved=inter)
             idx = {"om": 0, "o1": 0, "o2": 1, "os": 2}
             pn = subprocess.run([NEW] + argv("new_"), capture_output=True, timeout=120)
             assert pn.returncode == 0, (it, argv(""), pn.returncode, pn.stderr[-300:])
@@ -131,6 +132,12 @@ def run(iters=20, seed=1, verbose=True):
             assert [x for x in sn if x not in tn] == [x for x in sr if x not in tr], (it, argv(""), sn, sr)
             assert tn == ["Total input FastQ records: %d (%d pairs)" % (sizes[-1], sizes[-1] // 2)], (it, tn, sizes)
             assert len(tr) == 1 and any(tr[0] == "Total input FastQ records: %d (%d pairs)" % (z, z // 2) for z in sizes), (it, tr, sizes)
+            if not inter:  # the forward file alone through `sickle se` (the reference's SE driver crashes: derived expectation only)
+                bs = reference_batches(file_lines(datas[0]), reference_batch_len(len(datas[0]), 512, paired=False), 4)
+                want_se = b"".join(expected_se_output(bs, lambda f, r: cuts[0][r], T))
+                ps = subprocess.run([NEW, "se", "-f", paths[0], "-o", os.path.join(d, "new_se"), "-a", str(T)] + flags, capture_output=True, timeout=120)
+                assert ps.returncode == 0, (it, ps.stderr[-300:])
+                assert open(os.path.join(d, "new_se"), "rb").read() == want_se, (it, "se", T, flags)
             if verbose and it % 10 == 9:
                 print("iteration %d, %.0f s, short reference runs %d" % (it + 1, time.time() - t0, races), flush=True)
     if verbose:
