@@ -7,7 +7,7 @@ batch order, byte for byte; the reference -- whose per-batch output threads race
 whose main thread does not wait for the last of them -- must write a permutation of exactly those chunks in at
 least one of six runs (which pins the derivation to the reference), and its summary must equal ours.
 usage: soak_cli.py [iterations] [seed]"""
-import os, subprocess, sys, tempfile, time
+import gzip, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -72,19 +72,31 @@ def run(iters=20, seed=1, verbose=True):
                 flags.append("-x")
             if rng.integers(0, 2):
                 flags.append("-n")
+            gz = it % 8 >= 6  # gzip input (one member, or several): the batch budget follows the size of the FILE
+            ext = ".fastq.gz" if gz else ".fastq"
+
+            def put(name, data):
+                for old in (name + ".fastq", name + ".fastq.gz"):
+                    if os.path.exists(os.path.join(d, old)):
+                        os.remove(os.path.join(d, old))
+                if gz:
+                    level = int(rng.integers(1, 10))
+                    cutp = int(rng.integers(0, len(data) + 1)) if it % 16 >= 14 else len(data)
+                    data = gzip.compress(data[:cutp], level, mtime=0) + (gzip.compress(data[cutp:], level, mtime=0) if cutp < len(data) else b"")
+                open(os.path.join(d, name + ext), "wb").write(data)
             if inter:
-                open(os.path.join(d, "c.fastq"), "wb").write(b"".join(a + b for a, b in zip(r1, r2)))
+                put("c", b"".join(a + b for a, b in zip(r1, r2)))
                 outs = ["om", "os"]
-                argv = lambda pre: ["pe", "-c", os.path.join(d, "c.fastq"), "-m", os.path.join(d, pre + "om"), "-s", os.path.join(d, pre + "os"), "-a", str(T)] + flags  # noqa: E731
+                argv = lambda pre: ["pe", "-c", os.path.join(d, "c" + ext), "-m", os.path.join(d, pre + "om"), "-s", os.path.join(d, pre + "os"), "-a", str(T)] + flags  # noqa: E731
             else:
-                open(os.path.join(d, "f.fastq"), "wb").write(b"".join(r1))
-                open(os.path.join(d, "r.fastq"), "wb").write(b"".join(r2))
+                put("f", b"".join(r1))
+                put("r", b"".join(r2))
                 outs = ["o1", "o2", "os"]
-                argv = lambda pre: ["pe", "-f", os.path.join(d, "f.fastq"), "-r", os.path.join(d, "r.fastq"), "-o", os.path.join(d, pre + "o1"),  # noqa: E731
+                argv = lambda pre: ["pe", "-f", os.path.join(d, "f" + ext), "-r", os.path.join(d, "r" + ext), "-o", os.path.join(d, pre + "o1"),  # noqa: E731
                                     "-p", os.path.join(d, pre + "o2"), "-s", os.path.join(d, pre + "os"), "-a", str(T)] + flags
             # the expectation: per ingest batch, what `pe -a 1` writes for it
-            paths = [os.path.join(d, "c.fastq")] if inter else [os.path.join(d, "f.fastq"), os.path.join(d, "r.fastq")]
-            datas = [open(q, "rb").read() for q in paths]
+            paths = [os.path.join(d, "c" + ext)] if inter else [os.path.join(d, "f" + ext), os.path.join(d, "r" + ext)]
+            datas = [gzip.decompress(open(q, "rb").read()) if gz else open(q, "rb").read() for q in paths]
             po = ob.make_params(qt, thr, int(flags[5]), "-x" in flags, "-n" in flags)
             cuts = []
             for dat in datas:
@@ -92,7 +104,7 @@ def run(iters=20, seed=1, verbose=True):
                 c, e = ob.oracle_trim_batch(po, ql, sq, offsets=of)
                 assert e is None
                 cuts.append(c)
-            blen = reference_batch_len(len(datas[0]), 512, paired=True)
+            blen = reference_batch_len(os.path.getsize(paths[0]), 512, paired=True)
             b1 = reference_batches(file_lines(datas[0]), blen, 8 if inter else 4)
             b2 = None if inter else reference_batches(file_lines(datas[1]), blen, 4)
             chunks = expected_pe_outputs(b1, b2, lambda f, r: cuts[f][r], T, interleaved=inter)
@@ -133,7 +145,7 @@ def run(iters=20, seed=1, verbose=True):
             assert tn == ["Total input FastQ records: %d (%d pairs)" % (sizes[-1], sizes[-1] // 2)], (it, tn, sizes)
             assert len(tr) == 1 and any(tr[0] == "Total input FastQ records: %d (%d pairs)" % (z, z // 2) for z in sizes), (it, tr, sizes)
             if not inter:  # the forward file alone through `sickle se` (the reference's SE driver crashes: derived expectation only)
-                bs = reference_batches(file_lines(datas[0]), reference_batch_len(len(datas[0]), 512, paired=False), 4)
+                bs = reference_batches(file_lines(datas[0]), reference_batch_len(os.path.getsize(paths[0]), 512, paired=False), 4)
                 want_se = b"".join(expected_se_output(bs, lambda f, r: cuts[0][r], T))
                 ps = subprocess.run([NEW, "se", "-f", paths[0], "-o", os.path.join(d, "new_se"), "-a", str(T)] + flags, capture_output=True, timeout=120)
                 assert ps.returncode == 0, (it, ps.stderr[-300:])
