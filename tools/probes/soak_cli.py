@@ -144,6 +144,13 @@ def run(iters=20, seed=1, verbose=True):
             assert [x for x in sn if x not in tn] == [x for x in sr if x not in tr], (it, argv(""), sn, sr)
             assert tn == ["Total input FastQ records: %d (%d pairs)" % (sizes[-1], sizes[-1] // 2)], (it, tn, sizes)
             assert len(tr) == 1 and any(tr[0] == "Total input FastQ records: %d (%d pairs)" % (z, z // 2) for z in sizes), (it, tr, sizes)
+            if it % 5 == 0:  # -g: the outputs as gzip (BGZF blocks; deflated on the GPU on every other turn), same content
+                env = dict(os.environ, SICKLE_GZ_LEVEL="gpu") if it % 10 == 0 else None
+                pg = subprocess.run([NEW] + argv("gz_") + ["-g"], capture_output=True, timeout=120, env=env)
+                assert pg.returncode == 0, (it, pg.stderr[-300:])
+                for o in outs:
+                    z = open(os.path.join(d, "gz_" + o), "rb").read()
+                    assert gzip.decompress(z) == b"".join(c[idx[o]] for c in chunks), (it, o, "-g")
             if not inter:  # the forward file alone through `sickle se` (the reference's SE driver crashes: derived expectation only)
                 bs = reference_batches(file_lines(datas[0]), reference_batch_len(os.path.getsize(paths[0]), 512, paired=False), 4)
                 want_se = b"".join(expected_se_output(bs, lambda f, r: cuts[0][r], T))
