@@ -258,9 +258,9 @@ int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigne
     sk_ctx::ErrWord &w = ctx->stream_err[stream];
     if (!w.d) {
         SK_HIP(ctx, hipSetDevice(ctx->device));
-        SK_HIP(ctx, hipMalloc(&w.d, 6 * sizeof(unsigned long long)));
+        SK_HIP(ctx, hipMalloc(&w.d, 8 * sizeof(unsigned long long)));
         SK_HIP(ctx, hipMemset(w.d, 0xff, sizeof(unsigned long long))); // synchronous: done before any scan is enqueued
-        SK_HIP(ctx, hipMemset(w.d + 1, 0, 5 * sizeof(unsigned long long)));
+        SK_HIP(ctx, hipMemset(w.d + 1, 0, 7 * sizeof(unsigned long long)));
         SK_HIP(ctx, hipHostMalloc(&w.h, 6 * sizeof(unsigned long long), hipHostMallocDefault));
         *w.h = kNoError;
     }
@@ -386,16 +386,16 @@ int sk_create(int device, int slots, sk_ctx **out)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    SK_TRY(hipMalloc(&ctx->d_err, 6 * sizeof(unsigned long long)));
+    SK_TRY(hipMalloc(&ctx->d_err, 8 * sizeof(unsigned long long)));
     SK_TRY(hipMemset(ctx->d_err, 0xff, sizeof(unsigned long long)));
-    SK_TRY(hipMemset(ctx->d_err + 1, 0, 5 * sizeof(unsigned long long))); // the hand-over word (see enqueue_scan), four pair counters
+    SK_TRY(hipMemset(ctx->d_err + 1, 0, 7 * sizeof(unsigned long long))); // the hand-over word (see enqueue_scan), four pair counters, tiles left by the tile kernel
     SK_TRY(hipHostMalloc(&ctx->h_err, 6 * sizeof(unsigned long long), hipHostMallocDefault));
     *ctx->h_err = kNoError;
     ctx->slots.resize((size_t)slots);
     for (Slot &s : ctx->slots) {
-        SK_TRY(hipMalloc(&s.d_err, 2 * sizeof(unsigned long long)));
+        SK_TRY(hipMalloc(&s.d_err, 8 * sizeof(unsigned long long))); // the same block as the context's (words 2..5 unused)
         SK_TRY(hipMemset(s.d_err, 0xff, sizeof(unsigned long long)));
-        SK_TRY(hipMemset(s.d_err + 1, 0, sizeof(unsigned long long)));
+        SK_TRY(hipMemset(s.d_err + 1, 0, 7 * sizeof(unsigned long long)));
         SK_TRY(hipHostMalloc(&s.h_err, sizeof(unsigned long long), hipHostMallocDefault));
         SK_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         SK_TRY(hipEventCreateWithFlags(&s.finished, hipEventDisableTiming));

@@ -386,7 +386,13 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_team_kernel's
             // tell it that there is work: the word after the error word takes this scan's number (scans of a
             // stream are ordered and numbered upwards, so the word never needs a reset)
-            if (lane == 0) atomicMax(errword + 1, (unsigned long long)a.scan_id);
+            // ... and counts the tiles left, under the scan's number (word 6: number << 32 | count), so that the general
+            // kernel can tell a batch that was left to it whole
+            if (lane == 0) {
+                atomicMax(errword + 1, (unsigned long long)a.scan_id);
+                atomicMax(errword + 6, (unsigned long long)(a.scan_id & 0xffffffffull) << 32);
+                atomicAdd(errword + 6, 1ull);
+            }
             if (more && nxt.take) load_tile(qual, buf0, nxt);
             cur = nxt;
             continue;

@@ -57,16 +57,33 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
 // offsets[r], offsets[r + 1] / lengths[r] for a wave-uniform r through the scalar cache.  The compiler takes
 // vector loads for them (it cannot prove the arrays unwritten in a kernel that stores), and those would sit in
 // the vector-memory counter between the blocks in flight: every read boundary would drain the loader.
+template <typename T>
+__device__ __forceinline__ const T *in_sgprs(const T *p) // the address is the same in every lane: say so
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void scalar_load_pair(const uint64_t *p, uint64_t &x, uint64_t &y)
 {
     sk_v4u v;
+    p = in_sgprs(p);
     asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     x = ((uint64_t)v[1] << 32) | v[0];
     y = ((uint64_t)v[3] << 32) | v[2];
 }
+__device__ __forceinline__ uint64_t scalar_load(const unsigned long long *p)
+{
+    sk_v2u v;
+    p = in_sgprs(p);
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return ((uint64_t)v[1] << 32) | v[0];
+}
 __device__ __forceinline__ uint32_t scalar_load(const uint32_t *p)
 {
     uint32_t v;
+    p = in_sgprs(p);
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
@@ -138,8 +155,16 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
     // sk_scan_tile_any_kernel left -- if it left any: it has put this scan's number into the word after the
     // error word for every tile it skipped.  Runs rather than tiles so that the reads of one left-over tile
     // spread over the device; a wave asks the question for the tile its run lies in.
-    const bool leftovers = a.buf_bytes != 0;
-    if (leftovers && *reinterpret_cast<volatile unsigned long long *>(errword + 1) != a.scan_id) return;
+    // If the tile kernel left EVERY tile (word 6 of the error block: this scan's number << 32 | tiles left), the batch
+    // is a long-read batch that came without a hint: spans of equal cost, as if it had been declared.
+    // (Both words through the scalar cache -- written by the kernel before this one, and wave-uniform by construction:
+    // a vector load would make everything that depends on them look divergent to the compiler.)
+    bool leftovers = a.buf_bytes != 0;
+    if (leftovers) {
+        if (scalar_load(errword + 1) != a.scan_id) return;
+        const uint64_t c = scalar_load(errword + 6);
+        if ((uint32_t)(c >> 32) == (uint32_t)a.scan_id && (uint32_t)c == (uint32_t)((a.n_reads + 63) >> 6)) leftovers = false;
+    }
     uint64_t span_lo = 0, span_hi = 0;
     if (!leftovers) {
         const uint64_t g = blockIdx.x, G = gridDim.x, n = a.n_reads;

@@ -144,6 +144,22 @@ def test_both_general_kernels_on_every_length(sk_ctx, which, monkeypatch):
                 assert (out.cpu().numpy() == want).all()
             except capi.RangeError as e:
                 assert err is not None and (e.read, e.pos, e.ch) == tuple(err), (trial, hint, err, (e.read, e.pos, e.ch))
+    # a long-read batch that comes WITHOUT a hint: the tile kernel leaves every tile and counts them, the general
+    # kernel then cuts the batch into spans of equal cost as if the hint had been there
+    lens2 = rng.integers(2100, 9000, size=300).astype(np.uint64)
+    offs2 = np.zeros(301, dtype=np.uint64)
+    offs2[1:] = np.cumsum(lens2)
+    q3 = np.clip(rng.normal(60, 7, int(offs2[-1])).astype(int), 33, 74).astype(np.uint8)
+    for i in range(300):
+        q3[int(offs2[i]) + int(rng.integers(0, lens2[i])):int(offs2[i + 1])] = 38
+    want3, _ = ob.oracle_trim_batch(po, q3, None, offsets=offs2, threads=4)
+    dq3, do3 = torch.from_numpy(q3).cuda(), torch.from_numpy(offs2.view(np.int64)).cuda()
+    out3 = torch.empty((300, 2), dtype=torch.int32, device="cuda")
+    for hint in (0, 9000):
+        out3.fill_(-7)
+        sk_ctx.scan_device_async(p, dq3.data_ptr(), out3.data_ptr(), 300, offsets_ptr=do3.data_ptr(), stride=hint)
+        sk_ctx.scan_device_finish()
+        assert (out3.cpu().numpy() == want3).all(), hint
     # uniform fixed-stride batches (all reads, equal numbers of reads per wave)
     for L in (1024, 3000, 8192, 12_345):
         m = 50
