@@ -38,7 +38,7 @@ q = torch.randint(60, 74, (total + 65536,), dtype=torch.uint8, device=dev, gener
 q.view(-1)[: total].view(-1, 1000)[:, 800:] -= 25
 sq = torch.full((total + 65536,), 65, dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-for L in (600, 1000, 2000, 2048, 2049, 5000, 10_000, 30_000, 100_000):
+for L in (600, 1000, 2000, 2048, 2049, 5000, 10_000, 10_240, 30_000, 30_720, 100_000):
     n = total // L
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     report("uniform %d (stride %d)" % (L, L), timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, stream=s.cuda_stream)), n, n * (L + 8))
