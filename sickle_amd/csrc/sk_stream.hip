@@ -390,8 +390,56 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
             };
 
             bool have_block = false; // the block to scan has arrived already (the lockstep run below stopped at it)
+            // the block the first window ends in (lane r0 of it), if it is a whole block inside the read
+            const int j0 = wq >> 6, r0 = wq & 63;
+            const bool j0_plain = j0 < min(jf1, jtail);
 #pragma unroll 1
             for (j = 0; j < nbq; ++j, k4 += 256u) {
+                if (j == j0 && j0_plain && phase == (a.no5 ? 1 : 0) && pact && !pslow && ahead == DEPTH) {
+                    // ---- the first window's block, when nothing happens in it but the usual: window 0 is at/above the
+                    // threshold (trim.cpp:42: the 5' cut is found at once) and every later window of the block too.
+                    // One turn of the lockstep run below with three kinds of lanes: before the first window's end
+                    // (no window ends there), at it (window 0 alone), after it (a cell of 16 as everywhere).
+                    if (prem > 0) __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)(lds + pbase), 16, 0, SK_DMA_AUX);
+                    psrc += 1024;
+                    prem -= 1024;
+                    pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
+                    if (--pleft == 0) next_stream();
+                    wait_vmcnt_imm<DEPTH>();
+                    const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
+                    uint32_t sad = 0, sum = 0, part = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        sad = __builtin_amdgcn_sad_u8(d[u], min4, sad);
+                        sad = __builtin_amdgcn_sad_u8(d[u], max4, sad);
+                        sum = __builtin_amdgcn_sad_u8(d[u], 0u, sum);
+                        part = __builtin_amdgcn_sad_u8(d[u] & pm[u], 0u, part);
+                    }
+                    const uint32_t incl = wave_scan_add(sum);
+                    const uint32_t P = carry + incl - sum;
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = P;
+                    const uint32_t Pa = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table) + ((k4 - wq4) & tmask4));
+                    const int v = (int)(P + part - Pa) - T; // (meaningless in the lanes before r0)
+                    const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false); // wave_shr:1
+                    const int ai = lane - r0;
+                    const bool quiet = sad == clean && (ai < 0 || (ai == 0 ? v >= 0 : min(v, vp) >= B8));
+                    if (__builtin_amdgcn_ballot_w64(!quiet)) {
+                        ahead = DEPTH + 1; // loaded, arrived, not scanned: the general turn below takes it
+                        have_block = true;
+                    } else {
+                        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        vprev = __builtin_amdgcn_readlane(v, 63);
+                        if (phase == 0) {
+                            i0 = 0;
+                            phase = 1;
+                            five = first_char(0, true); // trim.cpp:46-51
+                            if (five == INF) five = 0;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        cbase = cbase + 1024u == ring_bytes ? 0u : cbase + 1024u;
+                        continue;
+                    }
+                }
                 if (phase == 1 && pact && !pslow && ahead == DEPTH && (uint32_t)(j - jf0) < nfast) {
                     // ---- lockstep run: the scan is in the usual blocks of its read (see below) and the loader in the
                     // middle of a stream, DEPTH blocks ahead.  One load, one counted wait, one block scanned per
