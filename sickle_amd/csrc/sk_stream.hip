@@ -490,6 +490,46 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                         have_block = true;
                     }
                 }
+                if (!have_block && j == nbq - 1 && j == jtail && j >= jf0 && phase == 1 && pact && !pslow && ahead == DEPTH) {
+                    // ---- the read's last block, when nothing happens in it either: every window that ends in it at/above
+                    // the threshold, the windows after the last aligned one too, no char out of range -- the read
+                    // keeps its 3' end (trim.cpp:13).  The lockstep turn with the read's end masked.
+                    if (prem > 0) __builtin_amdgcn_global_load_lds((gptr_t)psrc, (lptr_t)(lds + pbase), 16, 0, SK_DMA_AUX);
+                    psrc += 1024;
+                    prem -= 1024;
+                    pbase = pbase + 1024u == ring_bytes ? 0u : pbase + 1024u;
+                    if (--pleft == 0) next_stream();
+                    wait_vmcnt_imm<DEPTH>();
+                    const sk_v4u d = *reinterpret_cast<const sk_v4u *>(lds + cbase + lane16);
+                    const int x = 16 * (64 * j + lane);
+                    uint32_t sad = 0, sum = 0, part = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int n = L - x - 4 * u;
+                        const uint32_t xq = first_bytes(d[u], n, min4);
+                        sad = __builtin_amdgcn_sad_u8(xq, min4, sad);
+                        sad = __builtin_amdgcn_sad_u8(xq, max4, sad);
+                        sum = __builtin_amdgcn_sad_u8(first_bytes(d[u], n, 0u), 0u, sum);
+                        part = __builtin_amdgcn_sad_u8(d[u] & pm[u], 0u, part);
+                    }
+                    const uint32_t incl = wave_scan_add(sum);
+                    const uint32_t P = carry + incl - sum;
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(table) + (k4 & tmask4)) = P;
+                    const uint32_t Pa = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table) + ((k4 - wq4) & tmask4));
+                    const int v = (int)(P + part - Pa) - T;
+                    const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false); // wave_shr:1
+                    const bool val = x + wr <= L; // the aligned window that ends in this chunk exists
+                    const bool quiet = sad == clean && (!val || min(v, vp) >= B8);
+                    const int alast = (nwin - 1) >> 4, rem = nwin - 1 - 16 * alast;
+                    const int vt = __builtin_amdgcn_readlane(v, (alast + wq) & 63); // the last aligned window
+                    if (__builtin_amdgcn_ballot_w64(!quiet) || vt < rem * range) {
+                        ahead = DEPTH + 1; // loaded, arrived, not scanned: the general turn below takes it
+                        have_block = true;
+                    } else {
+                        tail_seen = true;
+                        break; // three stays L
+                    }
+                }
                 if (have_block) {
                     --ahead;
                     have_block = false;
