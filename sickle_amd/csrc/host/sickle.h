@@ -50,4 +50,16 @@ void msg(const std::string &content);
 // caller that embeds Trim_Single / Trim_Paired leaves it false and gets everything released.
 extern bool sickle_leave_fast;
 
+// The front process.  What the kernel does with a process that mapped gigabytes of input, pinned staging buffers
+// and held a HIP context takes 0.2-0.3 s after the last byte of output has been written and every output file
+// closed -- a fifth of a 20 M-read run, and nobody needs to wait for it.  So `sickle se|pe` forks before anything is
+// allocated or the GPU runtime touched: the child does the whole run; fatal_exit() in the child reports the exit
+// status through a pipe once the outputs are closed and stdout / stderr flushed and closed; the parent, which holds
+// nothing, leaves at once with that status, and the child's address space is torn down behind it.  A child that
+// ends any other way (a signal, a plain exit) is waited for and its status passed on; a parent that is killed
+// takes the child with it (PR_SET_PDEATHSIG).  SICKLE_NO_FRONT=1 runs everything in the one process, as before.
+// Returns in the process that is to do the work.
+void sickle_front_process();
+extern int sickle_done_fd;
+
 #endif

@@ -46,12 +46,14 @@ int main(int argc, char *argv[])
     } else if (strcmp(argv[1], "--help") == 0) {
         main_usage(EXIT_SUCCESS);
     } else if (strcmp(argv[1], "pe") == 0) {
+        sickle_front_process();
         sickle_leave_fast = true;
         static Trim_Paired trimmer; // static: not destroyed on the way out (fatal_exit does not unwind)
         retval = trimmer.parse_args(argc, argv);
         if (retval != 0) return retval;
         retval = trimmer.trim_main();
     } else {
+        sickle_front_process();
         sickle_leave_fast = true;
         static Trim_Single trimmer;
         retval = trimmer.parse_args(argc, argv);

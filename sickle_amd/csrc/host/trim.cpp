@@ -4,8 +4,12 @@
 #include "FqDeflate.h"
 #include "WorkerPool.h"
 
+#include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdlib>
@@ -30,6 +34,7 @@ void msg(const char *content)
 void msg(const std::string &content) { msg(content.c_str()); }
 
 bool sickle_leave_fast = false;
+int sickle_done_fd = -1;
 
 void fatal_exit(int status)
 {
@@ -37,7 +42,49 @@ void fatal_exit(int status)
     std::cerr.flush();
     fflush(stdout);
     fflush(stderr);
+    if (sickle_done_fd >= 0) { // sickle.h: the front process leaves with this status now
+        const unsigned char code = (unsigned char)status;
+        ::close(1); // whoever reads our stdout / stderr through a pipe sees their end now, not after the teardown
+        ::close(2);
+        (void)!::write(sickle_done_fd, &code, 1);
+        ::close(sickle_done_fd);
+    }
     _exit(status);
+}
+
+void sickle_front_process()
+{
+    const char *off = getenv("SICKLE_NO_FRONT");
+    if (off && *off && *off != '0') return;
+    // a profiler or any other preloaded library may have brought the GPU runtime up already: a fork would hand the
+    // child a runtime it cannot use
+    if (getenv("LD_PRELOAD") || getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES")) return;
+    int fds[2];
+    if (pipe(fds) != 0) return;
+    fflush(stdout);
+    fflush(stderr);
+    const pid_t parent = getpid();
+    const pid_t pid = fork();
+    if (pid < 0) {
+        ::close(fds[0]);
+        ::close(fds[1]);
+        return; // no second process: do the work here
+    }
+    if (pid == 0) {
+        ::close(fds[0]);
+        sickle_done_fd = fds[1];
+        prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (getppid() != parent) _exit(1); // the front process is gone already
+        return;
+    }
+    ::close(fds[1]);
+    unsigned char code = 0;
+    ssize_t n;
+    do n = ::read(fds[0], &code, 1); while (n < 0 && errno == EINTR);
+    if (n == 1) _exit(code);
+    int st = 0;
+    while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+    _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st));
 }
 
 // ---------------------------------------------------------------- OutFile

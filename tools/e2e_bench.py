@@ -99,11 +99,11 @@ def pe_against_reference(n_pairs, threads=None):
         res["input_bytes"] = os.path.getsize(p1) + os.path.getsize(p2)
         res["generate_s"] = time.perf_counter() - t0
 
-        def go(binary, tag, a):
+        def go(binary, tag, a, env=None):
             outs = [os.path.join(d, "%s_%s.fastq" % (tag, k)) for k in ("o1", "o2", "os")]
             t0 = time.perf_counter()
             pr = subprocess.run([binary, "pe", "-f", p1, "-r", p2, "-t", "sanger", "-o", outs[0], "-p", outs[1], "-s", outs[2],
-                                 "-a", str(a)], capture_output=True)
+                                 "-a", str(a)], capture_output=True, env=env)
             dt = time.perf_counter() - t0
             if pr.returncode != 0:
                 raise RuntimeError("%s exited %d: %s" % (binary, pr.returncode, pr.stderr.decode("latin-1")[-300:]))
@@ -117,6 +117,16 @@ def pe_against_reference(n_pairs, threads=None):
         res["new_aN_s"] = t_newn
         for o in o_newn:
             os.unlink(o)
+        # new_s is what the caller waits for: the CLI's front process leaves once the outputs are closed, the worker's
+        # address space (mapped input, pinned staging, HIP context) is torn down behind it.  The same run in ONE
+        # process, teardown included:
+        time.sleep(1.0)  # (the teardown of the run before is still going on)
+        t_single, o_single = go(NEW, "single", 1, env=dict(os.environ, SICKLE_NO_FRONT="1"))
+        res["new_single_process_s"] = t_single
+        res["new_s_is"] = "wall clock until the launching process gets control back, outputs complete and closed (front process, host/sickle.h)"
+        for o in o_single:
+            os.unlink(o)
+        time.sleep(1.0)
         if os.path.exists(REF):
             t_ref1, o_ref1 = go(REF, "ref1", 1)
             res["ref_a1_s"], res["ref_a1_reads_per_s"] = t_ref1, 2 * n_pairs / t_ref1
