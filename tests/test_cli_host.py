@@ -263,17 +263,21 @@ def test_empty_and_truncated_inputs(hostcheck, workdir):
             path = os.path.join(d, name)
             copy = os.path.join(d, "copy_" + name)
             open(copy, "wb").write(data)
-            # The reference's main thread does not wait for its last output thread (src/trim_paired.cpp:445-458):
-            # about one run in fifty leaves file 1 short.  A short file must be a prefix of ours; one complete run
-            # in six has to be there.
-            ours = open(os.path.join(d, name + ".out"), "rb").read()
+            # The reference's per-batch output threads race each other for the file (this 1 kB input is eight
+            # batches) and its main thread does not wait for the last of them (src/trim_paired.cpp:445-458): now and
+            # then file 1 comes out in another batch order, or short.  Every run must hold records of ours only, one
+            # run in six all of them (the order is pinned by the thread-order goldens and the soak, not here).
+            ours = sorted(parse_fastq(open(os.path.join(d, name + ".out"), "rb").read()))
             complete = False
             for attempt in range(6):
                 pr = subprocess.run([ob.REF_BIN, "pe", "-f", path, "-r", copy, "-t", "sanger", "-o", path + ".r1", "-p",
                                      path + ".r2", "-s", path + ".rs", "-a", "1"], capture_output=True, timeout=60)
                 assert pr.returncode == 0
-                theirs = open(path + ".r1", "rb").read()
-                assert ours.startswith(theirs), (name, attempt, len(theirs), len(ours))
+                try:
+                    theirs = sorted(parse_fastq(open(path + ".r1", "rb").read()))
+                except AssertionError:  # cut inside a record
+                    continue
+                assert all(r in ours for r in theirs), (name, attempt)
                 if theirs == ours:
                     complete = True
                     break
