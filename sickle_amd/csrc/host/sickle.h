@@ -60,6 +60,7 @@ extern bool sickle_leave_fast;
 // takes the child with it (PR_SET_PDEATHSIG).  SICKLE_NO_FRONT=1 runs everything in the one process, as before.
 // Returns in the process that is to do the work.
 void sickle_front_process();
+void sickle_wallclock_mark(const char *what);
 extern int sickle_done_fd;
 
 #endif

@@ -28,6 +28,7 @@ int main(int argc, char *argv[])
     // Batches are tens to hundreds of megabytes and are allocated and freed once per batch.
     // Keep such blocks inside the heap instead of mmap/munmap-ing (and page-faulting) them
     // every time: measured, this alone removes most of the system time of a run.
+    sickle_wallclock_mark("main");
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);

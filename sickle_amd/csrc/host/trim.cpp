@@ -5,6 +5,7 @@
 #include "WorkerPool.h"
 
 #include <errno.h>
+#include <time.h>
 #include <fcntl.h>
 #include <signal.h>
 #include <sys/prctl.h>
@@ -36,8 +37,20 @@ void msg(const std::string &content) { msg(content.c_str()); }
 bool sickle_leave_fast = false;
 int sickle_done_fd = -1;
 
+// SICKLE_STAGE_TIMES=1: the wall clock (CLOCK_REALTIME, what `date +%s.%N` shows) at main() and at the exit, so that a
+// script can tell start-up and teardown from the run
+void sickle_wallclock_mark(const char *what)
+{
+    const char *e = getenv("SICKLE_STAGE_TIMES");
+    if (!e || !*e || *e == '0') return;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    fprintf(stderr, "[wall] %-8s %ld.%09ld\n", what, (long)ts.tv_sec, ts.tv_nsec);
+}
+
 void fatal_exit(int status)
 {
+    sickle_wallclock_mark("exit");
     std::cout.flush();
     std::cerr.flush();
     fflush(stdout);
@@ -56,9 +69,12 @@ void sickle_front_process()
 {
     const char *off = getenv("SICKLE_NO_FRONT");
     if (off && *off && *off != '0') return;
-    // a profiler or any other preloaded library may have brought the GPU runtime up already: a fork would hand the
-    // child a runtime it cannot use
-    if (getenv("LD_PRELOAD") || getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES")) return;
+    // a profiler's preloaded tool library brings the GPU runtime up before main(): a fork would hand the child a
+    // runtime it cannot use
+    const char *pl = getenv("LD_PRELOAD");
+    if ((pl && (strstr(pl, "rocprof") || strstr(pl, "roctracer") || strstr(pl, "rocprofiler"))) || getenv("HSA_TOOLS_LIB") ||
+        getenv("ROCP_TOOL_LIBRARIES"))
+        return;
     int fds[2];
     if (pipe(fds) != 0) return;
     fflush(stdout);
