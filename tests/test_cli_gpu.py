@@ -46,6 +46,12 @@ def test_long_reads_byte_identical_on_gpu(workdir, name, general):
                  env=None if general == "default" else {"SK_GENERAL": general})
 
 
+@pytest.mark.parametrize("name", ["pe_fr_illumina", "pe_syn_mixed_inter_gz_illumina_n"])
+def test_reference_runs_in_one_process_on_gpu(workdir, name):
+    """SICKLE_NO_FRONT=1: the run and its teardown in the one process the caller started, same bytes."""
+    cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_NO_FRONT": "1"})
+
+
 def test_cli_soak_against_reference_on_gpu():
     """tools/probes/soak_cli.py with the product binary: 40 random paired inputs against the chunks derived from the
     oracle and against the compiled reference (which travels to the box as oracle/_ref)."""

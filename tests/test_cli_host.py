@@ -46,6 +46,27 @@ def test_long_reads_byte_identical(hostcheck, workdir, name):
     cu.check_run(hostcheck, workdir, name, cu.e2e()["long_reads"][name])
 
 
+@pytest.mark.parametrize("name", ["pe_fr_illumina", "pe_syn_mixed_inter_illumina_n", "pe_problem1_inter"])
+def test_reference_runs_in_one_process(hostcheck, workdir, name):
+    """SICKLE_NO_FRONT=1: no front process (host/sickle.h), the run and its teardown in the one process the caller
+    started -- the same bytes, summary and exit status as with it (every other test runs with the front process)."""
+    cu.check_run(hostcheck, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_NO_FRONT": "1"})
+
+
+def test_front_process_passes_the_exit_status_and_the_message(hostcheck, workdir):
+    """A fatal input error in the worker (exit(1) paths of FQEntry::validate): the front process leaves with status
+    1 and the reference's message is on stderr, complete, with and without it."""
+    bad = os.path.join(str(workdir), "front_bad.fastq")
+    open(bad, "wb").write(b"@r1\nACGT\n+\nIIII\n@r2\nACGTA\n+\nIIII\n")
+    outs = []
+    for env in (None, {"SICKLE_NO_FRONT": "1"}):
+        pr = cu.run_cli(hostcheck, workdir, ["se", "-f", bad, "-t", "sanger", "-o", os.path.join(str(workdir), "front_bad.out")], env=env)
+        assert pr.returncode == 1
+        assert b"[ERROR]" in pr.stderr
+        outs.append(pr.stderr)
+    assert outs[0] == outs[1]
+
+
 @pytest.mark.skipif(not ob.have_ref(), reason="needs the compiled reference (oracle/_ref)")
 def test_cli_soak_against_reference(hostcheck):
     """tools/probes/soak_cli.py, 80 random paired inputs (two files / interleaved; equal, mixed, long and tiny reads;
