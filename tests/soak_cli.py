@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak: random paired FASTQ files through the product CLI and through the compiled reference CLI (oracle/_ref/sickle,
+"""TEST INFRASTRUCTURE (uses the oracle / the compiled reference, like everything under tests/).  Soak: random paired FASTQ files through the product CLI and through the compiled reference CLI (oracle/_ref/sickle,
 `pe -a 1`).  Two files and interleaved; equal, mixed and long read lengths (uniform / segmented / ragged batches
 behind the CLI); every encoding; -q, -l, -x, -n.  The expectation is DERIVED (tests/fastq_util.py: the restated
 batch-cut rule + the oracle's cuts -> the output chunk of every ingest batch): this CLI must write the chunks in
@@ -8,7 +8,7 @@ whose main thread does not wait for the last of them -- must write a permutation
 least one of six runs (which pins the derivation to the reference), and its summary must equal ours.
 usage: soak_cli.py [iterations] [seed]"""
 import gzip, os, subprocess, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Soak: random long-read batches through both general kernels (SK_GENERAL=team|stream), host and device entry
+"""TEST INFRASTRUCTURE (uses the oracle / the compiled reference, like everything under tests/).  Soak: random long-read batches through both general kernels (SK_GENERAL=team|stream), host and device entry
 points, with and without longest-read hints, against the oracle.  usage: soak_general.py [iterations] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

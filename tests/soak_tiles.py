@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Soak: random short-read batches (1 .. 504 bp) through every layout of the lane-per-read kernels -- fixed stride
+"""TEST INFRASTRUCTURE (uses the oracle / the compiled reference, like everything under tests/).  Soak: random short-read batches (1 .. 504 bp) through every layout of the lane-per-read kernels -- fixed stride
 (aligned with an odd / even number of 8-byte units, packed back to back, with and without per-read lengths), ragged
 offsets (one length / mixed), segmented (cuts in read order and in slot order) -- against the oracle; every encoding,
 thresholds 0 .. 41, -l, -x, -n, chars out of range.  usage: soak_tiles.py [iterations] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -53,13 +53,11 @@ def test_reference_runs_in_one_process_on_gpu(workdir, name):
 
 
 def test_cli_soak_against_reference_on_gpu():
-    """tools/probes/soak_cli.py with the product binary: 40 random paired inputs against the chunks derived from the
+    """tests/soak_cli.py with the product binary: 40 random paired inputs against the chunks derived from the
     oracle and against the compiled reference (which travels to the box as oracle/_ref)."""
-    import sys
     import oracle_bind as ob
     if not ob.have_ref():
         pytest.skip("needs the compiled reference (oracle/_ref)")
-    sys.path.insert(0, os.path.join(cu.ROOT, "tools", "probes"))
     import soak_cli
     soak_cli.NEW = cu.PRODUCT_BIN
     assert soak_cli.run(40, 505, verbose=False) == 40

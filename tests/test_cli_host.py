@@ -69,11 +69,9 @@ def test_front_process_passes_the_exit_status_and_the_message(hostcheck, workdir
 
 @pytest.mark.skipif(not ob.have_ref(), reason="needs the compiled reference (oracle/_ref)")
 def test_cli_soak_against_reference(hostcheck):
-    """tools/probes/soak_cli.py, 80 random paired inputs (two files / interleaved; equal, mixed, long and tiny reads;
+    """tests/soak_cli.py, 80 random paired inputs (two files / interleaved; equal, mixed, long and tiny reads;
     every encoding; -q -l -x -n): this CLI writes the per-batch chunks derived from the oracle in batch order, the
     compiled reference a permutation of exactly those chunks, the summaries agree."""
-    import sys
-    sys.path.insert(0, os.path.join(cu.ROOT, "tools", "probes"))
     import soak_cli
     soak_cli.NEW = hostcheck
     assert soak_cli.run(80, 404, verbose=False) == 80

@@ -697,7 +697,7 @@ def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
     """(1) The read that a soak run caught: 137 bases, bad until the last 14 -- the first window at the threshold is
     one of those after the last aligned one, which a 64-window cell of the streaming kernel had already run through
     when the tail step looked at them again (phase "looking for the first S < T") and cut at a window BEFORE the 5'
-    one.  Next to a read long enough to send the batch to the general kernels.  (2) tools/probes/soak_general.py,
+    one.  Next to a read long enough to send the batch to the general kernels.  (2) tests/soak_general.py,
     300 random batches: every encoding, thresholds 0..41, -l, -x, -n, lengths 1..200 kb, chars out of range, both
     general kernels forced in turn, sk_submit and the device entry points with and without hints."""
     h = ("2f2d322f2d2c2c32312d312d322e2e302e31302f31322e2c2e322d2d2f322c312d2f2d2e302d2c2c2f32322f2f3230312c312e2c2d2e2c2f"
@@ -717,19 +717,15 @@ def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
             got = sk_ctx.trim_batch(p, q, None, offsets=offs)
             assert (got == want).all(), (which, before, after, got, want)
     monkeypatch.delenv("SK_GENERAL")
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools", "probes"))
     import soak_general
     assert soak_general.run(300, 2026, verbose=False) == 300 * 8
 
 
 def test_tile_kernels_soak(sk_ctx):
-    """tools/probes/soak_tiles.py, 400 random short-read batches through every layout of the lane-per-read kernels
+    """tests/soak_tiles.py, 400 random short-read batches through every layout of the lane-per-read kernels
     (fixed stride with an odd / even number of 8-byte units, packed, unaligned, with per-read lengths; ragged;
     segmented in read order and in slot order), every encoding, thresholds 0..41, -l, -x, -n, chars out of range.
     (18 000 such batches ran clean when the soak was written.)"""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "tools", "probes"))
     import soak_tiles
     assert soak_tiles.run(400, 2027, verbose=False) > 400 * 5
 
