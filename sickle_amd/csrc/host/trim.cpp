@@ -77,6 +77,20 @@ void sickle_front_process()
         return;
     int fds[2];
     if (pipe(fds) != 0) return;
+    // A caller may have started us with some of stdin / stdout / stderr closed: pipe() then hands out 0, 1 or 2, and
+    // the worker's summary or error text would go into the status pipe (the front process would leave with its
+    // first byte as the exit status).  Both ends go above 2.
+    for (int &fd : fds) {
+        if (fd > 2) continue;
+        const int up = fcntl(fd, F_DUPFD_CLOEXEC, 3);
+        if (up < 0) { // no descriptor to be had: do the work in this process
+            ::close(fds[0]);
+            ::close(fds[1]);
+            return;
+        }
+        ::close(fd);
+        fd = up;
+    }
     fflush(stdout);
     fflush(stderr);
     const pid_t parent = getpid();
@@ -354,7 +368,9 @@ int Abstract_Trimmer::open_device()
             }
         };
         std::thread pinner;
-        if (device_ids.size() == 1) pinner = std::thread(pin_all, false);
+        // (the context-free allocator pins through the current device of its thread, i.e. device 0: only there
+        // does the early pinning belong to the context the scans will run in)
+        if (device_ids.size() == 1 && device_ids[0] == 0) pinner = std::thread(pin_all, false);
         for (size_t g = 0; g < device_ids.size(); ++g) {
             const int rc = sk_create(device_ids[g], kSlots, &ctxs[g]);
             if (rc != SK_OK) {

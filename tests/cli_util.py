@@ -118,3 +118,51 @@ def check_run(binary, tmp, name, rec, summary=True, env=None):
         return re.sub(r"/tmp/tmp[^/\s]+/", "{tmp}/", s)
 
     assert norm(got) == norm(want), (name, got, want)
+
+
+EMBED_HOST = os.path.join(ROOT, "tests", "embed", "embed_host")  # oracle-backed shim, tests only
+EMBED_GPU = os.path.join(ROOT, "tests", "embed", "embed_gpu")    # the product library
+
+
+def build_embed(target):
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "embed"), os.path.join(ROOT, "tests", "embed", target)], check=True)
+    return os.path.join(ROOT, "tests", "embed", target)
+
+
+def check_embedded(binary, tmp, gpu):
+    """Trim_Paired / Trim_Single as a library (tests/embed/embed_main.cpp, the shape of reference src/sickle.cpp:61-80):
+    a PE golden, an SE run, another PE golden (mixed lengths, gzip input, -n) and the first one again, in ONE
+    process with everything released between them.  Every run's files must be the reference's; the device memory
+    and the resident set must not grow from run to run."""
+    import re
+    runs = e2e()["runs"]
+    plan = [("pe_syn_fr_sanger_n", runs["pe_syn_fr_sanger_n"]["argv"]),
+            ("se", ["se", "-f", "{inputs}/test.fastq", "-t", "illumina", "-o", "{tmp}/o1.fastq", "-a", "1"]),
+            ("pe_syn_mixed_inter_gz_illumina_n", runs["pe_syn_mixed_inter_gz_illumina_n"]["argv"]),
+            ("pe_syn_fr_sanger_n", runs["pe_syn_fr_sanger_n"]["argv"])]
+    argv = []
+    for k, (_, av) in enumerate(plan):
+        if k:
+            argv.append("--")
+        argv += [a.replace("{tmp}/o", "{tmp}/e%d_o" % k) for a in av]
+    pr = run_cli(binary, tmp, argv, env={"SICKLE_NO_FRONT": "1"})
+    text = pr.stderr.decode("latin-1")
+    assert pr.returncode == 0, text[-800:]
+    marks = re.findall(r"\[embed\] run (\d+) rc (-?\d+) device_free_bytes (-?\d+) rss_kb (-?\d+)", text)
+    assert [int(m[0]) for m in marks] == [0, 1, 2, 3] and all(int(m[1]) == 0 for m in marks), text[-800:]
+    for k, (name, _) in enumerate(plan):
+        want = runs["se_equiv_selfpair_illumina"]["outputs"] if name == "se" else runs[name]["outputs"]
+        for o, meta in want.items():
+            if name == "se" and o != "o1.fastq":
+                continue  # SURVEY F2: file 1 of the self-paired reference run is what `se` writes
+            p = os.path.join(str(tmp), "e%d_%s" % (k, o))
+            assert os.path.getsize(p) == meta["size"] and md5_file(p) == meta["md5"], (k, name, o)
+    free = [int(m[2]) for m in marks]
+    rss = [int(m[3]) for m in marks]
+    if gpu:
+        assert all(f > 0 for f in free), free
+        # everything a run allocated on the device is back after it: the runtime's own pools may keep a few MiB
+        assert min(free[1:]) >= free[0] - (32 << 20), free
+        assert free[3] >= free[0] - (8 << 20), free  # the same run again: no growth
+    assert rss[3] <= rss[0] + 96 * 1024, rss  # the same run again: the resident set does not creep (kB)
+    return marks

@@ -170,3 +170,16 @@ def test_malformed_record_in_a_later_batch_exits_1_on_gpu(workdir):
         pr = cu.run_cli(cu.PRODUCT_BIN, workdir, ["se", "-f", path, "-t", "sanger", "-o", "{tmp}/late_bad_out.fastq", "-a", threads])
         assert pr.returncode == 1, (pr.returncode, pr.stderr[-300:])
         assert b"[ERROR] Sequence and quality lines have different lengths:" in pr.stderr
+
+
+def test_drivers_embedded_as_a_library_on_gpu(workdir):
+    """Trim_Paired / Trim_Single of the PRODUCT build used the way reference src/sickle.cpp:61-80 uses them, four runs in
+    one process (PE, SE, PE with gzip input and -n, the first PE again), no front process, sickle_leave_fast false:
+    every run's files are the reference's, hipMemGetInfo after each run shows the device memory given back
+    (close_device / sk_destroy), and the resident set does not grow."""
+    import subprocess
+    binary = cu.build_embed("embed_gpu")
+    out = subprocess.run(["ldd", binary], capture_output=True).stdout.decode()
+    assert "libsickle_amd.so" in out and "libamdhip64" in out
+    marks = cu.check_embedded(binary, workdir, gpu=True)
+    print("embedded runs: device free / rss after each:", [(m[2], m[3]) for m in marks])

@@ -67,6 +67,26 @@ def test_front_process_passes_the_exit_status_and_the_message(hostcheck, workdir
     assert outs[0] == outs[1]
 
 
+def test_front_process_with_closed_standard_descriptors(hostcheck, workdir):
+    """A caller that starts sickle with stdin and stdout (or stdin and stderr) CLOSED: the status pipe of the
+    front process must not land on descriptor 1 or 2, where the worker's summary / error text would be taken
+    for the exit status (`<&- >&-` on a good input exited 10, `<&- 2>&-` on a bad one 91)."""
+    import subprocess
+    good = os.path.join(str(workdir), "fd_good.fastq")
+    bad = os.path.join(str(workdir), "fd_bad.fastq")
+    open(good, "wb").write(b"@r1\nACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIII\n" * 50)
+    open(bad, "wb").write(b"@r1\nACGT\n+\nIIII\n@r2\nACGTA\n+\nIIII\n")
+    out = os.path.join(str(workdir), "fd_out.fastq")
+    for env in ({}, {"SICKLE_NO_FRONT": "1"}):
+        e = dict(os.environ, **env)
+        for redirect in ("<&- >&-", "<&- 2>&-", "<&- >&- 2>&-"):
+            pr = subprocess.run("%s se -f %s -t sanger -o %s %s" % (hostcheck, good, out, redirect), shell=True, env=e, timeout=120)
+            assert pr.returncode == 0, (env, redirect, pr.returncode)
+            assert open(out, "rb").read() == open(good, "rb").read()
+            pr = subprocess.run("%s se -f %s -t sanger -o %s %s" % (hostcheck, bad, out, redirect), shell=True, env=e, timeout=120)
+            assert pr.returncode == 1, (env, redirect, pr.returncode)
+
+
 @pytest.mark.skipif(not ob.have_ref(), reason="needs the compiled reference (oracle/_ref)")
 def test_cli_soak_against_reference(hostcheck):
     """tests/soak_cli.py, 80 random paired inputs (two files / interleaved; equal, mixed, long and tiny reads;
@@ -465,3 +485,10 @@ def test_gzip_input_own_decoder_matches_zlib(hostcheck, workdir):
             pr = cu.run_cli(hostcheck, workdir, ["se", "-f", path, "-t", "illumina", "-o", o, "-b", "2", "-a", "2"], env=env)
             res.append((pr.returncode, open(o, "rb").read(), cu.summary_block(pr.stdout.decode()), pr.stderr))
         assert res[0] == res[1] == res[2] and res[0][0] == 0 and len(res[0][1]) > 1000000
+
+
+def test_drivers_embedded_as_a_library(workdir):
+    """reference src/sickle.cpp:61-80 as a library caller would write it: several Trim_Paired / Trim_Single runs in one
+    process, each trimmer on the stack, sickle_leave_fast false -- close_streams() / close_device() / the destructor
+    release everything (host build against the oracle-backed shim; tests/test_cli_gpu.py does the product)."""
+    cu.check_embedded(cu.build_embed("embed_host"), workdir, gpu=False)

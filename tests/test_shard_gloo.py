@@ -28,34 +28,43 @@ WORKER = textwrap.dedent("""
     import numpy as np, torch, torch.distributed as dist
     import oracle_bind as ob
     import bench                                               # the rank logic under test is bench.py's own
-    from sickle_amd import synth
+    from bench import wl
     from sickle_amd.shard import reduce_counters
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1"] + sys.argv[1:])
     plan = bench.job_plan(args, rank, world)
-    n_job = args.total_reads if plan["strong"] else args.reads * world
-    seq, qual = synth.make_reads(42, n_job, 150, "sanger")    # every rank can regenerate the job's reads
-    b, e = plan["lo"], plan["lo"] + plan["n"]
-    # the scan of this rank's shard (the oracle stands in for the GPU in this CPU test)
-    cuts, err = ob.oracle_trim_batch(ob.make_params("sanger"), qual[b:e].reshape(-1), stride=150, read_len=150, n_reads=e - b)
+    cpu = torch.device("cpu")
+    # this rank's reads, from bench.py's own generators (seeded per global read block), scanned by the oracle
+    # (which stands in for the GPU in this CPU test)
+    if args.workload == "mixed":
+        lens, qual, seq = wl.mixed_shard(torch, cpu, bench.SEED + 4, plan["lo"], plan["n"])
+        cuts, err = ob.oracle_trim_batch(ob.make_params("illumina", 20, 20, False, True), qual.numpy().reshape(-1), seq.numpy().reshape(-1),
+                                         stride=wl.MIX_HI, lengths=lens.numpy().astype(np.uint32), n_reads=plan["n"])
+        bases_in, algo = int(lens.sum()), 2 * int(lens.sum()) + 8 * plan["n"]
+    else:
+        qual = wl.se_shard(torch, cpu, bench.SEED, plan["lo"], plan["n"], 150, plan["stride"])
+        cuts, err = ob.oracle_trim_batch(ob.make_params("sanger"), qual.numpy().reshape(-1), stride=plan["stride"], read_len=150, n_reads=plan["n"])
+        bases_in, algo = 150 * plan["n"], 158 * plan["n"]
+    assert err is None
     kept = int((cuts[:, 1] >= 0).sum())
     bases = int(np.clip(cuts[:, 1] - cuts[:, 0], 0, None).sum())
-    counts, tmax = reduce_counters(dist, [kept, (e - b) - kept, bases, e - b], 0.5 + rank)
+    counts, tmax = reduce_counters(dist, [kept, plan["n"] - kept, bases, plan["n"], bases_in], 0.5 + rank)
+    h2d = bench.gather_floats(torch, dist, 10.0 + rank, None) if args.mode == "pipeline" else None
     if rank == 0:
-        res = bench.headline(args, plan, world, counts, tmax, [1.0, 2.0, 3.0], "test")
-        print(json.dumps({"counts": counts, "tmax": tmax, "line": res, "span": [b, e]}))
+        res = bench.headline(args, plan, world, counts, tmax, [] if args.mode == "pipeline" else [1.0, 2.0, 3.0], "test", algo, counts[4], h2d)
+        print(json.dumps({"counts": counts, "tmax": tmax, "line": res, "span": [plan["lo"], plan["lo"] + plan["n"]]}))
     dist.barrier()
     dist.destroy_process_group()
 """)
 
 
-def run_ranks(tmp_path, extra, port):
+def run_ranks(tmp_path, extra, port, world=2):
     import json
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)] + extra,
                         capture_output=True, timeout=300, env=env)
     assert pr.returncode == 0, pr.stderr.decode()[-2000:]
@@ -63,28 +72,38 @@ def run_ranks(tmp_path, extra, port):
     return json.loads(line)
 
 
-def oracle_counts(n):
+def oracle_counts(n, stride=152):
+    """kept and bases kept of reads [0, n) of bench.py's fixed-length job, generated in ONE piece."""
+    import torch
     import oracle_bind as ob
-    from sickle_amd import synth
-    seq, qual = synth.make_reads(42, n, 150, "sanger")
-    cuts, _ = ob.oracle_trim_batch(ob.make_params("sanger"), qual.reshape(-1), stride=150, read_len=150, n_reads=n)
+    import bench
+    qual = bench.wl.se_shard(torch, torch.device("cpu"), bench.SEED, 0, n, 150, stride)
+    cuts, _ = ob.oracle_trim_batch(ob.make_params("sanger"), qual.numpy().reshape(-1), stride=stride, read_len=150, n_reads=n)
     kept = int((cuts[:, 1] >= 0).sum())
     return kept, int(np.clip(cuts[:, 1] - cuts[:, 0], 0, None).sum())
 
 
 def test_two_ranks_strong_scaling_line(tmp_path):
     """bench.py --total-reads: the job's reads split into contiguous shards (BASELINE configs[3] shape), the
-    counters of the whole job on rank 0's line, throughput = all reads x steps over the slowest rank's time."""
-    got = run_ranks(tmp_path, ["--total-reads", "20001"], 29533)
-    kept, bases = oracle_counts(20001)
-    assert got["counts"] == [kept, 20001 - kept, bases, 20001]
+    counters of the whole job on rank 0's line -- the SAME kept / discarded as the job scanned in one piece (reads
+    are seeded by global block, not by rank) --, throughput = all reads x steps over the slowest rank's time."""
+    total = 3 * 65536 // 2 + 17  # the shard boundary falls inside a seed block
+    got = run_ranks(tmp_path, ["--total-reads", str(total)], 29533)
+    kept, bases = oracle_counts(total)
+    assert got["counts"][:4] == [kept, total - kept, bases, total]
     assert got["tmax"] == 1.5  # max over ranks
     line = got["line"]
     assert line["scaling"] == "strong" and line["n_gpus"] == 2
-    assert line["config"]["reads_in_job"] == 20001 and line["config"]["reads_per_gpu"] == 10001
-    assert "sharded across 2" in line["config"]["workload"]
-    assert abs(line["value"] - 20001 * 3 / 1.5) < 1e-6
+    assert line["config"]["reads_in_job"] == total and line["config"]["reads_per_gpu"] == (total + 1) // 2
+    assert "sharded across 2" in line["config"]["workload"] and "configs[3]" in line["config"]["workload"]
+    assert abs(line["value"] - total * 3 / 1.5) < 1e-4 * line["value"]
     assert line["kept"] == kept and line["roofline"]["kernel_ms_avg"] == 2.0
+    assert len(json_line(line)) < 2500
+
+
+def json_line(d):
+    import json
+    return json.dumps(d)
 
 
 def test_two_ranks_weak_scaling_line(tmp_path):
@@ -94,3 +113,26 @@ def test_two_ranks_weak_scaling_line(tmp_path):
     assert got["span"] == [0, 7001]
     assert line["scaling"] == "weak" and line["config"]["reads_in_job"] == 14002 and line["kept"] == kept
     assert "configs[1]" in line["config"]["workload"]
+
+
+def test_mixed_workload_same_totals_on_one_and_two_ranks(tmp_path):
+    """--workload mixed (BASELINE configs[4]'s batch: 75-301 bp, illumina, -n): strong scaling, and the two-shard job
+    keeps and discards exactly what the one-shard job does."""
+    one = run_ranks(tmp_path, ["--workload", "mixed", "--mixed-reads", "90001"], 29535, world=1)
+    two = run_ranks(tmp_path, ["--workload", "mixed", "--mixed-reads", "90001"], 29536, world=2)
+    assert one["counts"] == two["counts"] and one["counts"][3] == 90001
+    assert 0 < two["counts"][0] < 90001  # -n discards every read with an uppercase N: a real mix of kept and discarded
+    line = two["line"]
+    assert line["scaling"] == "strong" and "configs[4]" in line["config"]["workload"] and line["config"]["read_len"] == "75-301"
+    assert two["span"] == [0, 45001]
+    assert line["roofline"]["algorithmic_bytes_per_launch"] > 2 * 75 * 45001
+
+
+def test_pipeline_mode_line(tmp_path):
+    """--mode pipeline (configs[3]'s async batch pipeline): per-rank and total H2D rates on the line, the step named
+    as PCIe-inclusive."""
+    got = run_ranks(tmp_path, ["--mode", "pipeline", "--total-reads", "20001", "--batches", "8"], 29537)
+    line = got["line"]
+    assert line["config"]["mode"] == "pipeline" and "async batch pipeline: 8 batches per rank" in line["config"]["workload"]
+    assert line["h2d_GBps_per_rank"] == [10.0, 11.0] and line["h2d_GBps_total"] == 21.0
+    assert "PCIe" in line["metric"] and line["roofline"]["traffic"] is None

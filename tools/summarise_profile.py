@@ -31,21 +31,25 @@ json.dump(summary, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 stats = glob.glob(os.path.join(src, "trace/*/*kernel_stats.csv"))[0]
 shutil.copyfile(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
 shutil.copyfile(os.path.join(src, "trace_bench.json"), os.path.join(dst, "%s_bench_under_trace.json" % tag))
-# the stats file averages every launch of the run, the settle and warm-up launches included; the
-# timed launches are the last `steps` of the trace
+# the stats file averages every launch of the run, the settle and warm-up launches included (and the
+# pipeline leg's launches of the same kernel on smaller batches); the timed launches are the `steps`
+# that follow the settle + warm-up launches at the head of the trace
 trace = glob.glob(os.path.join(src, "trace/*/*kernel_trace.csv"))
 if trace:
     line = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
     # the headline kernel only (the default bench run also launches every variant's kernels): the name the
     # counter passes saw most often
     head = name.split("(")[0] if name else "sk_scan"
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(trace[0])) if r["Kernel_Name"].startswith(head)]
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0])) if r["Kernel_Name"].startswith(head))
+    d = [(e - s) / 1e6 for s, e in rows]
     k = line["steps"]
+    first = line.get("settle_launches", 0) + line.get("warmup", 0)
+    timed = d[first:first + k]
     json.dump({"kernel": head, "kernel_launches_in_trace": len(d), "avg_ms_all_launches": sum(d) / len(d), "timed_steps": k,
-               "avg_ms_timed_launches": sum(d[-k:]) / k, "bench_events_avg_ms_same_run": line["roofline"]["kernel_ms_avg"]},
+               "avg_ms_timed_launches": sum(timed) / k, "bench_events_avg_ms_same_run": line["roofline"]["kernel_ms_avg"]},
               open(os.path.join(dst, "%s_timed_launches.json" % tag), "w"), indent=1)
     print("trace: all %d launches avg %.4f ms, the %d timed ones %.4f ms, bench events %.4f ms" %
-          (len(d), sum(d) / len(d), k, sum(d[-k:]) / k, line["roofline"]["kernel_ms_avg"]))
+          (len(d), sum(d) / len(d), k, sum(timed) / k, line["roofline"]["kernel_ms_avg"]))
 for row in csv.DictReader(open(stats)):
     if "sk_scan" in row["Name"]:
         print(row["Name"][:60], "calls", row["Calls"], "avg ns", row["AverageNs"])
