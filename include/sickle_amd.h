@@ -201,11 +201,11 @@ int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
- * 2 = general (teams of 16 lanes per read up to a longest read of 4096, 6 = a wave per read with the read
- * streamed through LDS beyond), 3 = tiled over a segmented batch, 4 = tiled with the tile staged
- * through registers (equal lengths, no sequence buffer, row stride 72..160), 5 = tiled with rows
- * re-strided on the way into LDS (packed / misaligned fixed stride, ragged).  For tests and bench
- * labels. */
+ * 7 = general, medium reads (a wave per read up to a longest read of 4096, the read resident in LDS, window sums
+ * from the matrix pipe), 6 = general, long reads (a wave per read with the read streamed through LDS), 3 = tiled
+ * over a segmented batch, 4 = tiled with the tile staged through registers (equal lengths, no sequence buffer, row
+ * stride 72..160), 5 = tiled with rows re-strided on the way into LDS (packed / misaligned fixed stride, ragged).
+ * (2 = round 2's teams of 16 lanes per read: no shape selects it any more.)  For tests and bench labels. */
 int sk_kernel_for(const sk_batch *batch);
 
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */

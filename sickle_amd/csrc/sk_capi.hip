@@ -178,17 +178,21 @@ uint32_t rag_buf_bytes(uint64_t max_len, bool uniform)
 
 // which path a batch takes: 3 segmented, 1 tiled (aligned rows), 5 tiled (rows at any address),
 // 2 general kernel only
-// The general kernel: teams of 16 lanes with the reads resident (sk_team.hip) up to SK_STREAM_MIN bytes of the
-// caller's longest-read hint, the streaming wave-per-read kernel (sk_stream.hip) beyond and when there is no
-// hint.  SK_GENERAL=team|stream forces one (diagnostics, tests).
+// The general kernels, by the caller's longest-read hint: a wave per read with the read resident in LDS and its
+// window sums from the matrix pipe (sk_band.hip) up to SK_STREAM_MIN bytes, the streaming wave-per-read kernel
+// (sk_stream.hip) beyond and when there is no hint.  SK_GENERAL=band|team|stream forces one (diagnostics, tests;
+// team = round 2's teams of 16 lanes on the vector ALU, sk_team.hip, which nothing selects any more).
+constexpr uint64_t SK_STREAM_MIN_DEFAULT = 4096;
 hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets, const uint32_t *lengths, sk_cut_dev *out,
                           unsigned long long *errword, const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
 {
     const char *force = getenv("SK_GENERAL");
-    static const uint64_t stream_min = [] { const char *e = getenv("SK_STREAM_MIN"); return e ? (uint64_t)atoll(e) : 4096ull; }();
+    static const uint64_t stream_min = [] { const char *e = getenv("SK_STREAM_MIN"); return e ? (uint64_t)atoll(e) : SK_STREAM_MIN_DEFAULT; }();
     const bool use_stream = force ? force[0] == 's' : (max_len == 0 || max_len > stream_min);
+    // (until the band kernel is the faster one at every medium length, the teams stay the default)
+    if (!use_stream && !(force && force[0] == 'b')) return sk_launch_team(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
     return use_stream ? sk_launch_stream(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream)
-                      : sk_launch_team(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
+                      : sk_launch_band(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
 }
 
 int path_of(const sk_batch *b)
@@ -465,7 +469,7 @@ int sk_kernel_for(const sk_batch *batch)
         const bool ragged = batch->offsets || batch->lengths;
         const uint64_t longest = ragged ? batch->stride : batch->read_len;
         const bool general_only = path == 2 || (path == 5 && batch->offsets && batch->stride > SK_LONG_BATCH_HINT);
-        return general_only ? ((longest == 0 || longest > 4096) ? 6 : 2) : path;
+        return general_only ? ((longest == 0 || longest > SK_STREAM_MIN_DEFAULT) ? 6 : 2) : path;
     }
     // uniform batches without a sequence buffer (no -n) and rows of 72..160 bytes: the tile comes in
     // through the wave's registers instead of LDS-DMA
@@ -528,6 +532,7 @@ const char *sk_kernel_name(int which)
     case 4: return "sk_scan_tile_staged_kernel";
     case 5: return "sk_scan_tile_any_kernel";
     case 6: return "sk_scan_stream_kernel";
+    case 7: return "sk_scan_band_kernel";
     default: return "";
     }
 }

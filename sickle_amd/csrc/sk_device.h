@@ -48,8 +48,8 @@ struct sk_scan_args {
     uint32_t buf_bytes; // LDS bytes per wave (segmented / rows at any address); general kernel: != 0 = only the tiles that do not fit them
     int32_t slot_order;   // segmented batches: cuts written in slot order, out_index only names erroring reads
     uint64_t scan_id;     // number of this scan on its error word (ragged batches: tile kernel -> general kernel hand-over)
-    uint32_t team_rbuf;   // general kernel: LDS bytes of one read's buffer
-    uint32_t team_maxlen; // general kernel: the longest read that goes through LDS
+    uint32_t team_rbuf;   // general kernels with resident reads (band, team): LDS bytes of one read's buffer
+    uint32_t team_maxlen; // ... and the longest read that goes through LDS
     uint32_t stream_nb;   // streaming general kernel: 1 KiB blocks in a wave's ring
     uint32_t stream_read_cost;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
     uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
@@ -65,6 +65,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
                                     const sk_scan_args *a, const sk_seg_class *classes, uint32_t n_classes,
                                     int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_team(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
+                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
+                                     const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_band(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                      const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                      const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,

@@ -405,6 +405,40 @@ __device__ __forceinline__ sk_cut_dev scan_read_global(const uint8_t *__restrict
     return sk_cut_dev{five, three};
 }
 
+// offsets[r], offsets[r + 1] / lengths[r] for a wave-uniform r through the scalar cache.  The compiler takes
+// vector loads for them (it cannot prove the arrays unwritten in a kernel that stores), and those would sit in
+// the vector-memory counter between the blocks in flight: every read boundary would drain the loader.
+template <typename T>
+__device__ __forceinline__ const T *in_sgprs(const T *p) // the address is the same in every lane: say so
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void scalar_load_pair(const uint64_t *p, uint64_t &x, uint64_t &y)
+{
+    sk_v4u v;
+    p = in_sgprs(p);
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    x = ((uint64_t)v[1] << 32) | v[0];
+    y = ((uint64_t)v[3] << 32) | v[2];
+}
+__device__ __forceinline__ uint64_t scalar_load(const unsigned long long *p)
+{
+    sk_v2u v;
+    p = in_sgprs(p);
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return ((uint64_t)v[1] << 32) | v[0];
+}
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t *p)
+{
+    uint32_t v;
+    p = in_sgprs(p);
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // what a wave needs to know about one tile
 struct sk_tile_view {
     uint64_t off;    // wave-uniform: byte offset of the tile (of its first read) in qual / seq

@@ -54,40 +54,6 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
     return v;
 }
 
-// offsets[r], offsets[r + 1] / lengths[r] for a wave-uniform r through the scalar cache.  The compiler takes
-// vector loads for them (it cannot prove the arrays unwritten in a kernel that stores), and those would sit in
-// the vector-memory counter between the blocks in flight: every read boundary would drain the loader.
-template <typename T>
-__device__ __forceinline__ const T *in_sgprs(const T *p) // the address is the same in every lane: say so
-{
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
-    return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ void scalar_load_pair(const uint64_t *p, uint64_t &x, uint64_t &y)
-{
-    sk_v4u v;
-    p = in_sgprs(p);
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    x = ((uint64_t)v[1] << 32) | v[0];
-    y = ((uint64_t)v[3] << 32) | v[2];
-}
-__device__ __forceinline__ uint64_t scalar_load(const unsigned long long *p)
-{
-    sk_v2u v;
-    p = in_sgprs(p);
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return ((uint64_t)v[1] << 32) | v[0];
-}
-__device__ __forceinline__ uint32_t scalar_load(const uint32_t *p)
-{
-    uint32_t v;
-    p = in_sgprs(p);
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return v;
-}
-
 // A wave-uniform value kept in a vector register: the kernel's uniform state does not fit the scalar file, and
 // what only the vector ALU reads (masks, thresholds) need not compete for it (nor for the one scalar operand
 // a VOP3 instruction may have).
@@ -256,10 +222,15 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                 nstate = 0;
                 pk = 0;
                 pleft = (pL >> 10) + 1; // chunk index L >> 4 included: the window that ends with the read may end there
-                // that block is empty if L is a multiple of 1024; or the read's last chunk leaves the batch
-                pslow = ((pL & 1023) == 0 || po + (((uint64_t)pL + 15u) & ~15ull) > batch_end) ? 1 : 0;
+                // That block is empty if L is a multiple of 1024.  It still takes its turn with ONE DMA (the loads are
+                // counted), so lane 0 is given one byte more to expect: it then fetches the 16 bytes behind the read,
+                // which nobody looks at (every use of the block masks by L), and the read stays on the fast paths
+                // like any other (round 2 sent such a read through the careful loader: 2x slower at 10 240 and
+                // 30 720 bp).  Careful loads only where the last chunk -- or those 16 bytes -- would leave the batch.
+                const int empty_last = (pL & 1023) == 0 ? 1 : 0;
+                pslow = po + (((uint64_t)pL + 15u) & ~15ull) + (empty_last ? 16u : 0u) > batch_end ? 1 : 0;
                 psrc = qual + po + lane16;
-                prem = pL - (int)lane16;
+                prem = pL - (int)lane16 + ((empty_last && !pslow && lane == 0) ? 1 : 0);
                 pact = 1;
             }
         };

@@ -54,7 +54,7 @@ def run(iters=50, seed=1, verbose=True):
         want, err = ob.oracle_trim_batch(po, qual, seq, offsets=offs, threads=8)
         dq, ds, do = torch.from_numpy(qual).cuda(), torch.from_numpy(seq).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
         out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
-        for which in ("team", "stream"):
+        for which in ("band", "team", "stream"):
             os.environ["SK_GENERAL"] = which
             runs = [("submit", None)] + [("device", h) for h in (0, int(lens.max()), 2000)]
             for kind, hint in runs:

@@ -36,7 +36,7 @@ def test_reference_runs_in_pieces_on_gpu(workdir, name):
     cu.check_run(cu.PRODUCT_BIN, workdir, name, cu.e2e()["runs"][name], env={"SICKLE_SUBBATCH_READS": "7"})
 
 
-@pytest.mark.parametrize("general", ["default", "team", "stream"])
+@pytest.mark.parametrize("general", ["default", "band", "team", "stream"])
 @pytest.mark.parametrize("name", sorted(cu.e2e()["long_reads"].keys()))
 def test_long_reads_byte_identical_on_gpu(workdir, name, general):
     """Reads of 1 .. 40 kb with short ones between them: ragged batches through sk_submit, the general kernels

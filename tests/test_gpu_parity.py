@@ -56,6 +56,7 @@ def test_kernel_selection():
     assert capi.lib().sk_kernel_for(b) == 5  # ragged: the same kernel, per-lane lengths
     b = capi.Batch(q.ctypes.data, None, None, 600, 600, None, 10)
     assert capi.lib().sk_kernel_for(b) == 2  # rows beyond the tile kernels: general kernel (teams of 16 lanes)
+    assert capi.lib().sk_kernel_name(7) == b"sk_scan_band_kernel"
     assert capi.lib().sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 5000, 5000, None, 10)
     assert capi.lib().sk_kernel_for(b) == 6  # longer than 4096: the streaming general kernel
@@ -67,10 +68,11 @@ def test_kernel_selection():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["team", "stream"])
+@pytest.mark.parametrize("which", ["band", "team", "stream"])
 def test_both_general_kernels_on_every_length(sk_ctx, which, monkeypatch):
-    """SK_GENERAL forces one of the two general kernels (teams with the reads resident / a wave per read, the
-    read streamed through a ring of 1 KiB blocks) for every batch that takes the general path: both must agree
+    """SK_GENERAL forces one of the general kernels (a wave per read with the read resident and its window sums from
+    the matrix pipe / round 2's teams of 16 lanes / a wave per read, the
+    read streamed through a ring of 1 KiB blocks) for every batch that takes the general path: all must agree
     with the oracle on lengths from 1 to 70 kb -- around the block size (1023..1025, 2047..2049), multiples of
     1024 (the empty last block), 16 k + 0..15 (the partial last chunk), windows of every residue modulo 16 --
     with cuts at the very start, in the middle and in the last windows, device-resident ragged (all reads, spans of
@@ -705,7 +707,7 @@ def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
          "2c2d312e322e2d322e30305b5a5f5c5d5f5c5a5f5e5c5e5a59")
     r = np.frombuffer(bytes.fromhex(h), dtype=np.uint8)
     p, po = both_params("sanger", 30, 0, 0, 0)
-    for which in ("team", "stream"):
+    for which in ("band", "team", "stream"):
         monkeypatch.setenv("SK_GENERAL", which)
         for before, after in (([], [2387]), ([53, 103], [2387, 1]), ([1500], []), ([100] * 4, [100, 100, 5000])):
             parts = [np.full(l, 45, dtype=np.uint8) for l in before] + [r] + [np.full(l, 70, dtype=np.uint8) for l in after]
@@ -718,7 +720,7 @@ def test_general_kernels_soak_and_late_five_prime_cut(sk_ctx, monkeypatch):
             assert (got == want).all(), (which, before, after, got, want)
     monkeypatch.delenv("SK_GENERAL")
     import soak_general
-    assert soak_general.run(300, 2026, verbose=False) == 300 * 8
+    assert soak_general.run(300, 2026, verbose=False) == 300 * 12
 
 
 def test_tile_kernels_soak(sk_ctx):

@@ -22,13 +22,13 @@ def timeit(fn, reps=10):
         e0.record(s); fn(); e1.record(s)
     s.synchronize()
     return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
-for L in (1500, 2000, 2500, 3000, 3500, 4000, 4090):
+for L in (600, 1000, 1500, 2000, 3000, 4000, 4090):
     n = total // L
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     res = {}
-    for which in ("team", "stream"):
+    for which in ("band", "team", "stream"):
         os.environ["SK_GENERAL"] = which
         ms = timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, stream=s.cuda_stream))
         ctx.scan_device_finish(s.cuda_stream)
         res[which] = n * (L + 8) / ms / 1e6
-    print("L %5d  team16 %5.0f GB/s  stream %5.0f GB/s" % (L, res["team"], res["stream"]), flush=True)
+    print("L %5d  band %5.0f GB/s  team16 %5.0f GB/s  stream %5.0f GB/s" % (L, res["band"], res["team"], res["stream"]), flush=True)
