@@ -360,6 +360,43 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                 }
             };
 
+            // The 16 windows that END in this lane's chunk kc of block jb (the block at cbase), i.e. 16 (at - 1) + 1 .. 16 at
+            // with at = kc - wq >= 1, evaluated exactly: 4 windows per dword with the byte-parallel arithmetic of the tile
+            // kernels.  The chars entering are the 16 bytes from offset wr of chunk kc - 1 on (five aligned dword reads,
+            // v_alignbyte), the chars leaving are chunk at - 1, S - T starts from the aligned window before (vpl).
+            // -> bit (16 - u): window 16 (at - 1) + u is below the threshold, u = 1..16.  ~60 vector instructions for the
+            // block's 1024 windows, whatever the data: what a block costs when the averages HOVER at the threshold
+            // (cell by cell -- `cell` above, 64 windows per call -- round 2 ran such reads at 0.95 TB/s).
+            auto dense16 = [&](int jb, int kc, int vpl) -> uint32_t {
+                auto ringaddr = [&](int pos) -> uint32_t { // of the dword that holds read position pos (in block jb or before)
+                    int a_ = (int)cbase + (pos - (jb << 10));
+                    if (a_ < 0) a_ += (int)ring_bytes;
+                    return (uint32_t)a_ & ~3u;
+                };
+                const int pin = 16 * (kc - 1) + wr; // the first char entering: window 16 (at - 1) + 1 ends with it
+                uint32_t e[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) e[u] = *reinterpret_cast<const uint32_t *>(lds + ringaddr((pin & ~3) + 4 * u));
+                const sk_v4u yv = *reinterpret_cast<const sk_v4u *>(lds + ringaddr(16 * (kc - wq - 1)));
+                int vv = vpl;
+                uint32_t M = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t xin = __builtin_amdgcn_alignbyte(e[u + 1], e[u], (uint32_t)(wr & 3));
+                    const int dd = (int)(((xin | H4) - yv[u]) ^ H4); // per byte: entering - leaving as int8 (both < 128)
+                    const int t1 = __builtin_amdgcn_sdot4(dd, 0x00000001, vv, false);
+                    const int t2 = __builtin_amdgcn_sdot4(dd, 0x00000101, vv, false);
+                    const int t3 = __builtin_amdgcn_sdot4(dd, 0x00010101, vv, false);
+                    const int t4 = __builtin_amdgcn_sdot4(dd, 0x01010101, vv, false);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t1, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t2, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t3, 31);
+                    M = __builtin_amdgcn_alignbit(M, (uint32_t)t4, 31);
+                    vv = t4;
+                }
+                return M & 0xffffu;
+            };
+
             bool have_block = false; // the block to scan has arrived already (the lockstep run below stopped at it)
             // the block the first window ends in (lane r0 of it), if it is a whole block inside the read
             const int j0 = wq >> 6, r0 = wq & 63;
@@ -446,8 +483,16 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                         const int vp = __builtin_amdgcn_update_dpp(vprev, v, 0x138, 0xf, 0xf, false); // wave_shr:1
                         const bool quiet = min(v, vp) >= B8 && sad == clean;
                         if (__builtin_amdgcn_ballot_w64(!quiet)) {
-                            ev = true;
-                            break;
+                            // not bounded away from the threshold.  If every char is in range the block is evaluated exactly
+                            // here (every lane of a block of the run has its cell), and the run goes on unless a window
+                            // below the threshold shows: a read that hovers ABOVE the threshold stays in the run
+                            bool stay = false;
+                            if (__builtin_amdgcn_ballot_w64(sad != clean) == 0)
+                                stay = __builtin_amdgcn_ballot_w64(dense16(j + done, (int)(k4 >> 2), vp) != 0) == 0;
+                            if (!stay) {
+                                ev = true;
+                                break;
+                            }
                         }
                         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         vprev = __builtin_amdgcn_readlane(v, 63);
@@ -607,6 +652,45 @@ sk_scan_stream_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restric
                             pbch = (int)(int8_t)ringbyte(pb);
                         }
                         int cur = 0;
+                        if (phase < 2 && __builtin_popcountll(phase == 0 ? m_ge : m_lt) > 2) {
+                            // ---- many cells flagged: the averages HOVER at the threshold.  Every lane evaluates ITS cell exactly
+                            // (dense16); window order = lane order, so the read's state steps by ballots.
+                            const int at = k - wq; // this lane's aligned window: 16 at (val: it exists)
+                            uint32_t lt16 = 0, ge16 = 0; // bit (31 - (u - 1)): window 16 (at - 1) + u is below / at-or-above T, u = 1..16
+                            if (val && at >= 1) {
+                                lt16 = dense16(j, k, vp) << 16;
+                                ge16 = ~lt16 & 0xffff0000u;
+                            } else if (val && at == 0) { // window 0 alone: as u = 16 of the cell "before the read"
+                                lt16 = v < 0 ? 0x00010000u : 0u;
+                                ge16 = v < 0 ? 0u : 0x00010000u;
+                            }
+                            int after_from = phase == 1 ? -1 : INF; // windows strictly after this one may be the first S < T
+                            if (phase == 0) { // trim.cpp:42
+                                const uint64_t m = __builtin_amdgcn_ballot_w64(ge16 != 0);
+                                if (m) {
+                                    const int t = __builtin_ctzll(m);
+                                    i0 = 16 * (64 * j + t - wq - 1) + 1 + (int)__builtin_clz((uint32_t)__builtin_amdgcn_readlane((int)ge16, t));
+                                    phase = 1;
+                                    after_from = i0;
+                                    five = first_char(i0, true); // trim.cpp:46-51
+                                    if (five == INF) five = 0;
+                                }
+                            }
+                            if (phase == 1) { // trim.cpp:61
+                                const int rel = after_from - 16 * (at - 1); // this lane's windows u <= rel are not after it
+                                const uint32_t aft = rel <= 0 ? ~0u : (rel >= 32 ? 0u : ~0u >> rel);
+                                const uint32_t cand = lt16 & aft;
+                                const uint64_t m = __builtin_amdgcn_ballot_w64(cand != 0);
+                                if (m) {
+                                    const int t = __builtin_ctzll(m);
+                                    i1 = 16 * (64 * j + t - wq - 1) + 1 + (int)__builtin_clz((uint32_t)__builtin_amdgcn_readlane((int)cand, t));
+                                    phase = 2;
+                                    three = first_char(i1, false); // trim.cpp:65-70
+                                    if (three == INF) three = L;
+                                }
+                            }
+                            cur = 64;
+                        }
                         while (phase < 2 && cur < 64) {
                             const uint64_t m = (phase == 0 ? m_ge : m_lt) & (~0ull << cur);
                             if (!m) break;

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 LENS=${1:-"600 1000 2000"}
 cd /tmp && export TMPDIR=/tmp
 for L in $LENS; do
-  for K in band team; do
+  for K in ${KERNELS:-band team}; do
     OUT=$ROOT/gpurun_out/medium_pmc_${K}_$L
     rm -rf $OUT; mkdir -p $OUT
     i=0
