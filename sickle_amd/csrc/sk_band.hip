@@ -67,8 +67,12 @@ __device__ __forceinline__ void band_other(const uint8_t *qual, const uint8_t *s
 
 } // namespace
 
-// LEFT: only the reads of the 64-read tiles sk_scan_tile_any_kernel left (a.buf_bytes != 0)
-template <bool HAS_SEQ, bool LEFT>
+// LEFT: only the reads of the 64-read tiles sk_scan_tile_any_kernel left (a.buf_bytes != 0).
+// UNI: a batch of equal lengths at a fixed stride (no offsets, no lengths; every read goes through the ring): the
+// read's place, its window width, the band and the number of loads per read are the same for all, so nothing is
+// looked up, no slot has a header, one band serves both chains -- the per-read bookkeeping of the general form is
+// most of what it spends on a 1 kb read (the scalar unit, one per CU, is its bound).
+template <bool HAS_SEQ, bool LEFT, bool UNI>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 sk_scan_band_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                     const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
@@ -170,7 +174,7 @@ sk_scan_band_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     auto turn = [&](bool on0, int w0, uint32_t at0, bool on1, int w1, uint32_t at1, int mybase, int mynwin, uint32_t &lt, uint32_t &ge) {
         uint32_t p0 = 0, p1 = 0;
         if (on0) p0 = chain(band0, w0, at0);
-        if (on1) p1 = chain(band1, w1, at1);
+        if (on1) p1 = chain(UNI ? band0 : band1, w1, at1);
         // lanes 0..31 keep chain 0's columns, lanes 32..63 chain 1's: s[0] = windows 0..15 of the lane's column,
         // s[1] = windows 16..31; bit (31 - s) of M: window mybase + s is below the threshold
         const sk_v2u sw = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
@@ -412,34 +416,52 @@ sk_scan_band_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     uint32_t islot = 0, cslot = 0, inring = 0;
     int inflight = 0;
     bool drained = false;
+    // UNI: reads n_ring and beyond do not go through the ring (the batch's last read when the 16-byte chunks of its
+    // image would reach past the batch): wave 0 takes them at the end
+    const uint64_t n_ring = UNI ? a.n_reads - ((a.n_reads && (uint64_t)a.stride * (a.n_reads - 1) + (((uint64_t)a.read_len + 15u) & ~15ull) > batch_end) ? 1u : 0u) : 0;
+    uint64_t r_issue = blockIdx.x, r_head = blockIdx.x; // UNI: the next read to issue / the read at the head of the ring
     auto issue = [&]() {
         uint64_t r = 0, o = 0;
         int L = 0;
-        if (!advance(r, o, L)) {
-            drained = true;
-            return;
-        }
-        if (lane == 0) *reinterpret_cast<sk_v4u *>(headers + 4u * islot) = sk_v4u{(uint32_t)r, (uint32_t)L, (uint32_t)o, (uint32_t)(o >> 32)};
-        if (staged(L, o)) {
+        if (UNI) {
+            if (r_issue >= n_ring) {
+                drained = true;
+                return;
+            }
             uint8_t *nb = lds + islot * slot_bytes;
-            stage(qual, o, L, nb);
-            if (HAS_SEQ) stage(seq, o, L, nb + rb);
-            inflight += pieces_of(L);
+            stage(qual, r_issue * a.stride, (int)a.read_len, nb);
+            if (HAS_SEQ) stage(seq, r_issue * a.stride, (int)a.read_len, nb + rb);
+            r_issue += gridDim.x;
+        } else {
+            if (!advance(r, o, L)) {
+                drained = true;
+                return;
+            }
+            if (lane == 0) *reinterpret_cast<sk_v4u *>(headers + 4u * islot) = sk_v4u{(uint32_t)r, (uint32_t)L, (uint32_t)o, (uint32_t)(o >> 32)};
+            if (staged(L, o)) {
+                uint8_t *nb = lds + islot * slot_bytes;
+                stage(qual, o, L, nb);
+                if (HAS_SEQ) stage(seq, o, L, nb + rb);
+                inflight += pieces_of(L);
+            }
         }
         islot = islot + 1u == NSLOT ? 0u : islot + 1u;
         ++inring;
     };
-    auto header = [&](uint32_t slot, sk_band_read &x, uint64_t &o) {
-        const sk_v4u h = *reinterpret_cast<const sk_v4u *>(headers + 4u * slot);
-        x.r = (uint32_t)__builtin_amdgcn_readfirstlane((int)h[0]);
-        x.L = __builtin_amdgcn_readfirstlane((int)h[1]);
-        o = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)h[3]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)h[2]);
+    auto fresh = [&](sk_band_read &x, uint32_t r, int L, uint32_t slot) {
+        x.r = r;
+        x.L = L;
         x.buf = slot * slot_bytes;
-        x.w = window_of(x.L);
-        x.nwin = x.L - x.w + 1;
+        x.w = window_of(L);
+        x.nwin = L - x.w + 1;
         x.phase = a.no5 ? 1 : 0;
         x.i0 = a.no5 ? -1 : INF;
         x.i1 = INF;
+    };
+    auto header = [&](uint32_t slot, sk_band_read &x, uint64_t &o) {
+        const sk_v4u h = *reinterpret_cast<const sk_v4u *>(headers + 4u * slot);
+        o = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)h[3]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)h[2]);
+        fresh(x, (uint32_t)__builtin_amdgcn_readfirstlane((int)h[0]), __builtin_amdgcn_readfirstlane((int)h[1]), slot);
     };
     // the wave's next turn: x (and, two == true, y) are the reads at the head of the ring, already taken off its
     // counters; `pending` = vector-memory instructions of the reads still behind them.  A short read (at most 1024
@@ -448,13 +470,25 @@ sk_scan_band_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
     sk_band_read x, y;
     bool two = false;
     int pending = 0;
+    const int uni_pieces = UNI ? pieces_of((int)a.read_len) : 0;
     auto fetch = [&]() -> bool {
         for (;;) {
             while (!drained && inring < NSLOT) issue();
             if (inring == 0) return false;
+            const uint32_t nslot = cslot + 1u == NSLOT ? 0u : cslot + 1u;
+            if (UNI) {
+                fresh(x, (uint32_t)r_head, (int)a.read_len, cslot);
+                y = x;
+                two = x.nwin <= 1024 && inring >= 2;
+                if (two) fresh(y, (uint32_t)(r_head + gridDim.x), (int)a.read_len, nslot);
+                r_head += (two ? 2u : 1u) * (uint64_t)gridDim.x;
+                inring -= two ? 2u : 1u;
+                pending = (int)inring * uni_pieces;
+                cslot = two ? (nslot + 1u == NSLOT ? 0u : nslot + 1u) : nslot;
+                return true;
+            }
             uint64_t ox, oy;
             header(cslot, x, ox);
-            const uint32_t nslot = cslot + 1u == NSLOT ? 0u : cslot + 1u;
             if (!staged(x.L, ox)) {
                 band_other<HAS_SEQ>(qual, seq, ox, x.L, x.r, out, errword, a);
                 cslot = nslot;
@@ -476,13 +510,15 @@ sk_scan_band_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict_
             return true;
         }
     };
+    if (UNI && blockIdx.x == 0 && n_ring < a.n_reads) // (the batch's last read, see n_ring)
+        band_other<HAS_SEQ>(qual, seq, n_ring * a.stride, (int)a.read_len, n_ring, out, errword, a);
     bool have = fetch();
     while (have) {
         // ---- the bands of the two chains are built here, for every turn that follows with the same two window widths
         // (inside the loop of turns a conditional rebuild makes the compiler keep two copies of both sets: 60 registers)
         const int w0 = x.w, w1 = y.w;
         build_band(band0, w0);
-        build_band(band1, w1);
+        if (!UNI) build_band(band1, w1);
         do {
             wait_vmcnt(pending); // loads return in order: everything older than the later reads' pieces has landed
             // two reads: a chain each.  One read: both chains, 2048 windows per turn, until both windows are found
@@ -551,6 +587,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_band(const
                            errword, at);
         return hipGetLastError();
     };
-    if (a->buf_bytes) return has_seq ? launch(sk_scan_band_kernel<true, true>) : launch(sk_scan_band_kernel<false, true>);
-    return has_seq ? launch(sk_scan_band_kernel<true, false>) : launch(sk_scan_band_kernel<false, false>);
+    if (a->buf_bytes) return has_seq ? launch(sk_scan_band_kernel<true, true, false>) : launch(sk_scan_band_kernel<false, true, false>);
+    // equal lengths at a fixed stride, every read with something to scan and short enough for a slot: the lean form
+    if (!offsets && !lengths && a->read_len > 0 && a->read_len >= (uint32_t)a->lthr && a->read_len <= at.team_maxlen)
+        return has_seq ? launch(sk_scan_band_kernel<true, false, true>) : launch(sk_scan_band_kernel<false, false, true>);
+    return has_seq ? launch(sk_scan_band_kernel<true, false, false>) : launch(sk_scan_band_kernel<false, false, false>);
 }

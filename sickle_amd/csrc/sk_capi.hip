@@ -158,6 +158,8 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->stream_nb = 0;
     a->stream_read_cost = 0;
     a->stream_tbl = 0;
+    static const uint32_t seg_shift = [] { const char *e = getenv("SK_SEG_CHUNK_SHIFT"); return e ? (uint32_t)atoi(e) : 2u; }();
+    a->seg_chunk_shift = seg_shift > 6u ? 6u : seg_shift;
     return SK_OK;
 }
 

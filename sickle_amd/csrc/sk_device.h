@@ -53,6 +53,7 @@ struct sk_scan_args {
     uint32_t stream_nb;   // streaming general kernel: 1 KiB blocks in a wave's ring
     uint32_t stream_read_cost;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
     uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
+    uint32_t seg_chunk_shift; // segmented batches: a wave takes 1 << this consecutive tiles at a time
 };
 
 // internal to libsickle_amd.so (not part of the C ABI)

@@ -298,9 +298,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // wave takes SEG_CHUNK consecutive tiles at a time.  There the tiles are sorted by length, and with single
     // steps every wave met a new length at every tile (its tiles lie `waves` apart) and rebuilt the band matrix
     // each time (set_length: ~150 instructions against ~600 for the tile's scan); a chunk shares one length.
-    constexpr uint64_t SEG_CHUNK = 4;
+    const uint64_t SEG_CHUNK = 1ull << a.seg_chunk_shift;
     auto next_tile = [&](uint64_t tt) -> uint64_t {
-        if (SEG) return ((tt + 1) % SEG_CHUNK != 0) ? tt + 1 : tt + 1 + (wave_count - 1) * SEG_CHUNK;
+        if (SEG) return ((tt + 1) & (SEG_CHUNK - 1)) != 0 ? tt + 1 : tt + 1 + (wave_count - 1) * SEG_CHUNK;
         return tt + wave_count;
     };
     uint64_t t = SEG ? wave_global * SEG_CHUNK : wave_global;
@@ -868,7 +868,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
         int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
         if (per_cu > 16) per_cu = 16;
         uint64_t grid = (uint64_t)cu_count * per_cu;
-        const uint64_t chunks = ((uint64_t)k.n_tiles + 3) / 4; // a wave takes 4 consecutive tiles at a time (SEG_CHUNK)
+        const uint64_t chunk = 1ull << a->seg_chunk_shift; // a wave takes this many consecutive tiles at a time (SEG_CHUNK)
+        const uint64_t chunks = ((uint64_t)k.n_tiles + chunk - 1) / chunk;
         if (grid > chunks) grid = chunks;
         sk_scan_args as = *a;
         as.buf_bytes = lds_bytes;

@@ -72,6 +72,13 @@ out = torch.empty((n, 2), dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 report("uniform 150 staged (random quals)", timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=152, read_len=150, stream=s.cuda_stream)), n, n * 158)
 del q, out
+m = 4_000_000
+for L, st in ((250, 264), (301, 312), (75, 88)):  # the uniform LDS-DMA kernel on the same kind of data as the segmented cases below
+    q = torch.randint(40, 74, (m, st), dtype=torch.uint8, device=dev)
+    out = torch.empty((m, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    report("uniform %d (stride %d, random quals)" % (L, st), timeit(lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), m, stride=st, read_len=L, stream=s.cuda_stream)), m, m * (L + 8))
+    del q, out
 seg_case("segmented: all 150 (one class), 10 M", [(150, n)], p)
 seg_case("segmented: all 150, shuffled out_index", [(150, n)], p, shuffle_out=True)
 seg_case("segmented: all 250, 4 M", [(250, 4_000_000)], p)
