@@ -32,8 +32,29 @@ const char *const kTypeNames[4] = {"Phred", "Sanger", "Solexa", "Illumina"};
 constexpr unsigned long long kNoError = ~0ull;
 constexpr uint32_t SK_SEG_MAX_CLASSES = 16;
 
+// device scratch of the regrouping of mixed-length ragged batches (sk_sort.hip): one per stream of scans
+struct SortScratch {
+    uint64_t *perm = nullptr;            // 8 lists x cap_list tiles x 64 entries
+    unsigned long long *lists = nullptr; // 8 lists x cap_list descriptors of 32 bytes
+    uint32_t *counts = nullptr;          // tiles per list [8], flags [2]
+    size_t cap_list = 0;
+    void release_lists()
+    {
+        if (perm) (void)hipFree(perm);
+        if (lists) (void)hipFree(lists);
+        perm = nullptr, lists = nullptr, cap_list = 0;
+    }
+    void release()
+    {
+        release_lists();
+        if (counts) (void)hipFree(counts);
+        counts = nullptr;
+    }
+};
+
 struct Slot {
     bool busy = false;
+    SortScratch sort;
     uint8_t *d_qual = nullptr, *d_seq = nullptr;
     size_t cap_bytes = 0;
     uint64_t *d_offsets = nullptr;
@@ -62,7 +83,9 @@ struct sk_ctx {
     // not meet in one word (each sk_scan_device_finish reports what ITS stream's scans found)
     struct ErrWord {
         unsigned long long *d = nullptr, *h = nullptr; // d: error word, hand-over word, four pair counters (6 x 8 bytes)
+        SortScratch sort;
     };
+    SortScratch sort0; // ... of the NULL stream
     std::map<hipStream_t, ErrWord> stream_err;
     std::mutex stream_err_lock;
     std::vector<Slot> slots;
@@ -73,7 +96,7 @@ struct sk_ctx {
 namespace {
 
 // the error word (device, pinned host copy) of the device-resident scans on `stream`
-int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h);
+int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h, SortScratch **sort = nullptr);
 
 void set_error(sk_ctx *ctx, const char *fmt, ...)
 {
@@ -160,6 +183,7 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->stream_tbl = 0;
     static const uint32_t seg_shift = [] { const char *e = getenv("SK_SEG_CHUNK_SHIFT"); return e ? (uint32_t)atoi(e) : 2u; }();
     a->seg_chunk_shift = seg_shift > 6u ? 6u : seg_shift;
+    a->sort_flags = nullptr;
     return SK_OK;
 }
 
@@ -219,8 +243,39 @@ bool tile_eligible(const sk_batch *b)
 // a device-resident batch is taken for a long-read batch when the caller's longest-read hint is beyond
 // SK_LONG_BATCH_HINT -- 64 CONSECUTIVE reads of at most 2 040 bases do not occur in one.
 #define SK_LONG_BATCH_HINT 4096u
+// the longest read whose 64-row image fits a wave buffer of `buf` bytes (== rag_tile_fits of the kernels)
+uint32_t rag_fit_len(uint32_t buf)
+{
+    uint32_t best = 0;
+    for (uint32_t L = 16; L <= SK_RAG_MAX_LEN; L += 16)
+        if (64u * 16u * ((L >> 4) | 1u) + SK_TILE_SLACK <= buf) best = L;
+    return best;
+}
+
+// scratch for a regrouping of n reads; false (and no sorting) if it cannot be had
+bool ensure_sort(sk_ctx *ctx, SortScratch &s, uint64_t n)
+{
+    // per list: the tiles of every eighth window, at most SK_SORT_WINDOW / 64 full ones + one partial one per class each;
+    // 32 bytes of descriptor and 64 x 8 bytes of entries per tile (~9 bytes per read as the lists fill, 13 at worst)
+    const size_t windows = (size_t)((n + SK_SORT_WINDOW - 1) / SK_SORT_WINDOW);
+    const size_t per_list = ((windows + 7) / 8) * (SK_SORT_WINDOW / 64 + 64) + 8;
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    if (!s.counts && hipMalloc(&s.counts, 16 * sizeof(uint32_t)) != hipSuccess) return false;
+    if (per_list > s.cap_list) {
+        s.release_lists();
+        const size_t cap = per_list + (per_list >> 3);
+        if (hipMalloc(&s.lists, 8 * cap * 4 * sizeof(unsigned long long)) != hipSuccess) return false;
+        if (hipMalloc(&s.perm, 8 * cap * 64 * sizeof(uint64_t)) != hipSuccess) {
+            s.release_lists();
+            return false;
+        }
+        s.cap_list = cap;
+    }
+    return true;
+}
+
 int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_dev *out, unsigned long long *d_err,
-                 hipStream_t stream, int rag_fit = -1)
+                 hipStream_t stream, int rag_fit = -1, SortScratch *sort = nullptr)
 {
     if (a->n_reads == 0) return SK_OK;
     const uint8_t *seq = a->truncn ? b->seq : nullptr;
@@ -243,7 +298,25 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         // b->stride of an `offsets` batch is the caller's hint of the longest read (0 = unknown); with
         // stride + lengths it bounds the reads; packed uniform batches: the read length is known
         ar.buf_bytes = rag_buf_bytes(ragged ? b->stride : b->read_len, !ragged);
+        // A big `offsets` batch is regrouped first (sk_sort.hip: windows of 8192 reads counting-sorted by window width,
+        // 8 bytes of scratch per read).  If that finds reads of different lengths -- and none too long for the tiles --
+        // the sorted scan below takes the batch on the matrix path and the two kernels after it return at once; a
+        // batch of one length (or with long reads) is theirs as before and the sorted scan returns.  SK_SORT=0: never.
+        static const bool sort_on = [] { const char *e = getenv("SK_SORT"); return !(e && *e == '0'); }();
+        static const uint64_t sort_min = [] { const char *e = getenv("SK_SORT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)SK_SORT_MIN_READS; }(); // (tests lower it)
+        const bool sorted = sort_on && sort && b->offsets && a->n_reads >= sort_min && ensure_sort(ctx, *sort, a->n_reads);
+        if (sorted) {
+            uint32_t fit = rag_fit_len(ar.buf_bytes);
+            if (b->stride && b->stride < fit) fit = b->stride;
+            SK_HIP(ctx, sk_launch_sort(b->offsets, a->n_reads, fit, sort->perm, sort->lists, (uint32_t)sort->cap_list, sort->counts, stream));
+            ar.sort_flags = sort->counts + 8;
+        }
         SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
+        if (sorted) {
+            sk_scan_args as = ar;
+            as.n_tiles = (uint32_t)sort->cap_list;
+            SK_HIP(ctx, sk_launch_sorted(b->qual, seq, b->offsets, sort->perm, sort->lists, sort->counts, out, d_err, &as, ctx->cu_count, stream));
+        }
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)
         if (ragged) SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, b->stride, ctx->cu_count, stream));
@@ -253,11 +326,12 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
     return SK_OK;
 }
 
-int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h)
+int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigned long long **h, SortScratch **sort)
 {
     if (stream == nullptr) {
         *d = ctx->d_err;
         *h = ctx->h_err;
+        if (sort) *sort = &ctx->sort0;
         return SK_OK;
     }
     std::lock_guard<std::mutex> lock(ctx->stream_err_lock);
@@ -272,6 +346,7 @@ int err_word_of(sk_ctx *ctx, hipStream_t stream, unsigned long long **d, unsigne
     }
     *d = w.d;
     *h = w.h;
+    if (sort) *sort = &w.sort;
     return SK_OK;
 }
 
@@ -427,6 +502,7 @@ void sk_destroy(sk_ctx *ctx)
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_err) (void)hipFree(s.d_err);
         if (s.h_err) (void)hipHostFree(s.h_err);
+        s.sort.release();
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.finished) (void)hipEventDestroy(s.finished);
     }
@@ -435,7 +511,9 @@ void sk_destroy(sk_ctx *ctx)
     for (auto &kv : ctx->stream_err) {
         if (kv.second.d) (void)hipFree(kv.second.d);
         if (kv.second.h) (void)hipHostFree(kv.second.h);
+        kv.second.sort.release();
     }
+    ctx->sort0.release();
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     delete ctx;
@@ -599,9 +677,10 @@ int sk_scan_device_async(sk_ctx *ctx, const sk_params *params, const sk_batch *b
     // caller queued there (e.g. the kernels that produced the batch)
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     unsigned long long *d_err, *h_err;
-    rc = err_word_of(ctx, stream, &d_err, &h_err);
+    SortScratch *sort = nullptr;
+    rc = err_word_of(ctx, stream, &d_err, &h_err, &sort);
     if (rc != SK_OK) return rc;
-    return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), d_err, stream);
+    return enqueue_scan(ctx, &a, batch, reinterpret_cast<sk_cut_dev *>(out), d_err, stream, -1, sort);
 }
 
 int sk_scan_device_finish(sk_ctx *ctx, void *hip_stream, sk_err *err)
@@ -732,7 +811,7 @@ int sk_submit(sk_ctx *ctx, int slot, const sk_params *params, const sk_batch *ba
         dev.classes = s.classes.data();
         dev.n_classes = (uint32_t)s.classes.size();
     }
-    rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute, rag_fit);
+    rc = enqueue_scan(ctx, &a, &dev, s.d_out, s.d_err, ctx->compute, rag_fit, &s.sort);
     if (rc != SK_OK) return rc;
     if (n) SK_HIP(ctx, hipMemcpyAsync(out, s.d_out, n * sizeof(sk_cut_dev), hipMemcpyDeviceToHost, ctx->compute));
     SK_HIP(ctx, hipMemcpyAsync(s.h_err, s.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->compute));

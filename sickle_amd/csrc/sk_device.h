@@ -16,6 +16,8 @@
 #define SK_RAG_MAX_LEN 2040            /* longest read the lane-per-read kernel takes from a ragged batch */
 #define SK_RAG_BUF_DEFAULT (20u * 1024u) /* LDS bytes per wave for ragged tiles when the caller gives no length hint */
 #define SK_RAG_BUF_MAX (40u * 1024u)
+#define SK_SORT_WINDOW 8192  /* reads per window of the device-side regrouping of mixed-length ragged batches (sk_sort.hip) */
+#define SK_SORT_MIN_READS 65536u /* ragged batches below this keep the plain tile kernel */
 
 struct sk_cut_dev {
     int32_t five, three;
@@ -54,6 +56,8 @@ struct sk_scan_args {
     uint32_t stream_read_cost;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
     uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
     uint32_t seg_chunk_shift; // segmented batches: a wave takes 1 << this consecutive tiles at a time
+    const uint32_t *sort_flags; // ragged batches behind the device-side regrouping: {windows of mixed lengths, reads too long for the tiles}; the
+                                // plain tile kernel (and the general kernel behind it) return at once when the sorted scan runs, and vice versa
 };
 
 // internal to libsickle_amd.so (not part of the C ABI)
@@ -77,6 +81,12 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
+// mixed-length ragged batches: the per-window regrouping (sk_sort.hip) and the scan of its tiles (sk_kernels.hip)
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sort(const uint64_t *offsets, uint64_t n_reads, uint32_t max_len, uint64_t *perm,
+                                     unsigned long long *lists, uint32_t list_cap, uint32_t *counts, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sorted(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets, const uint64_t *perm,
+                                       const unsigned long long *lists, const uint32_t *counts, sk_cut_dev *out,
+                                       unsigned long long *errword, const sk_scan_args *a, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_pair_count(const sk_cut_dev *cuts, uint64_t n_pairs, uint8_t *classes,
                                            unsigned long long *counters, int cu_count, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_read_probe(const void *buf, size_t bytes, uint32_t *sink, int cu_count,

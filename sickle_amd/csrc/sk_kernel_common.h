@@ -230,11 +230,13 @@ __device__ __forceinline__ uint32_t rag_pitch(uint32_t len)
 }
 
 // one LDS-DMA of the re-striding loader: 16 bytes per lane (uniform lengths) or 4
-template <bool WIDE>
+// KEEP: default cache policy instead of nt -- for the gathered rows of a regrouped batch, whose first and last 128-byte
+// lines are shared with the neighbouring reads and are to be found in the XCD's L2 by the tile that takes those
+template <bool WIDE, bool KEEP = false>
 __device__ __forceinline__ void dma_piece(const uint8_t *g, uint8_t *l)
 {
-    if (WIDE) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, SK_DMA_AUX);
-    else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, SK_DMA_AUX);
+    if (WIDE) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, KEEP ? 0 : SK_DMA_AUX);
+    else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, KEEP ? 0 : SK_DMA_AUX);
 }
 
 // One tile = reads [64t, 64t+64) of a batch whose rows start at any byte address (`offsets`, or a

@@ -91,13 +91,19 @@
 // (6.4 TB/s), whereas reading unaligned rows out of LDS costs 8x per ds_read.  Uniform lengths keep
 // the matrix path; per-lane lengths walk the vector-ALU path.  A tile whose image does not fit the
 // wave's buffer (long reads) is left to sk_scan_team_kernel.
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG>
+// SORT (a ragged batch regrouped by sk_sort.hip; RAG with a row start per lane): the tiles come from the list of this
+// workgroup's XCD -- {window, first slot, rows, window width} -- and a tile's rows are the reads perm[] names: equal in
+// window width, not in length, anywhere inside their window of SK_SORT_WINDOW consecutive reads.  One band per tile,
+// so the matrix path; lengths, window counts and the masks of the range check stay per lane.  (tiles = the lists,
+// out_index = perm, lengths = the lists' tile counts.)
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                   const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                   unsigned long long *errword, const sk_scan_args &a, const sk_tile_dev *__restrict__ tiles,
                   const uint32_t *__restrict__ out_index, const uint64_t *__restrict__ offsets)
 {
+    static_assert(!SORT || (RAG && !UNIFORM && MFMA), "regrouped ragged batches: re-strided tiles, matrix path");
     static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
     static_assert(!MFMA || UNIFORM || RAG, "the matrix path needs one window width per tile");
     // MIXED (ragged batches): per-lane lengths in general, but a tile whose 64 reads have ONE length --
@@ -122,9 +128,13 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     uint8_t *buf0 = lds + (size_t)wave * LDS_BUFS * buf_bytes;
     uint8_t *buf1 = LDS_BUFS > 1 ? buf0 + buf_bytes : buf0;
 
-    const uint64_t n_tiles = SEG ? (uint64_t)a.n_tiles : (a.n_reads + 63) >> 6;
-    uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
-    const uint64_t wave_count = (uint64_t)gridDim.x * waves_per_block;
+    // SORT: the list of XCD x = blockIdx mod 8 (single-wave workgroups), shared by the workgroups b = x, x + 8, ...
+    const uint32_t xcd = SORT ? blockIdx.x & 7u : 0u;
+    const unsigned long long *const slist = reinterpret_cast<const unsigned long long *>(tiles) + (size_t)xcd * a.n_tiles * 4u;
+    const uint64_t *const perm = reinterpret_cast<const uint64_t *>(out_index) + (size_t)xcd * a.n_tiles * 64u;
+    const uint64_t n_tiles = SORT ? (uint64_t)min(scalar_load(lengths + xcd), a.n_tiles) : SEG ? (uint64_t)a.n_tiles : (a.n_reads + 63) >> 6;
+    uint64_t wave_global = SORT ? (uint64_t)(blockIdx.x >> 3) : (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t wave_count = SORT ? (uint64_t)((gridDim.x - xcd + 7u) >> 3) : (uint64_t)gridDim.x * waves_per_block;
     if (a.tile_order == 1 && (wave_count & 7) == 0) {
         // workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD group a
         // contiguous run of wave slots, so that it streams a contiguous eighth of every stripe
@@ -209,6 +219,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             v.bytes = (v.rows - 1u) * stride + a.read_len;
             v.len = (int)a.read_len;
             v.r = (tt << 6) + lane;
+        } else if (SORT) {
+            // (sort_issue / sort_finish below: the loads go out a tile ahead)
         } else if (RAG) {
             const sk_rag_tile g = rag_probe(tt, lane, offsets, lengths, a);
             v.off = g.start;
@@ -231,6 +243,39 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         return v;
     };
 
+    // SORT: a tile's descriptor (32 bytes through the scalar cache) and its 64 entries (8 bytes per lane) lie where the
+    // tile's number says, so both loads go out together -- at the top of the turn BEFORE, ahead of the wait for that
+    // turn's tile (vmcnt(1) leaves the entry load in flight) -- and the entries are looked at when that turn's scan is
+    // over: the first version took descriptor, window bounds and entries one after the other at the start of every
+    // scan, 2-3 us of exposed latency per tile.
+    struct sort_raw {
+        sk_v4u d0, d1; // the descriptor's eight dwords (scalar registers)
+        uint64_t e;    // this lane's entry
+    };
+    auto sort_issue = [&](uint64_t tt) -> sort_raw {
+        sort_raw q;
+        const unsigned long long *dp = in_sgprs(slist + 4u * tt);
+        // (waited for here: at the top of a turn the wait for the turn's tile follows and covers it; a scalar register
+        // with its load still pending is nothing the compiler could be kept from copying)
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(q.d0), "=&s"(q.d1) : "s"(dp) : "memory");
+        q.e = perm[tt * 64u + (uint32_t)lane];
+        return q;
+    };
+    auto sort_finish = [&](sort_raw q) -> sk_tile_view {
+        sk_tile_view v;
+        const uint64_t widx = q.d0[0];
+        v.rows = (q.d0[1] >> 16) & 0xffu;
+        v.off = ((uint64_t)q.d0[3] << 32) | q.d0[2];
+        v.bytes = q.d1[1] ? 0xffffffffu : q.d1[0];
+        v.rowoff = (uint32_t)lane < v.rows ? (uint32_t)q.e : 0u;
+        v.len = (uint32_t)lane < v.rows ? (int)((uint32_t)(q.e >> 32) & 0xffffu) : 0;
+        v.r = widx * SK_SORT_WINDOW + (uint32_t)(q.e >> 48);
+        v.ts = rag_pitch<false>((uint32_t)wave_max(v.len));
+        v.take = true; // (the sort sends a batch with a read too long for the tiles to the other kernels)
+        v.uni = true;  // here: ONE window width
+        return v;
+    };
+
     // segmented batches scatter their cuts back to the caller's read order.  The descriptor is a scalar
     // load (not counted by vmcnt: it can be issued before the wait for the tile); the index is a vector
     // load that needs the descriptor, issued after that wait, when the descriptor has long arrived
@@ -250,21 +295,23 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
         const uint8_t *src = base + v.off;
         const uint32_t lim = (v.bytes ? v.bytes : 1u) - 1u;
+        // (a tile whose last byte is followed by 16 more of the batch: no chunk of it can leave the caller's buffer)
+        const bool all_safe = v.off + (uint64_t)lim + 1u + GRAN <= batch_end; // wave-uniform
         for (uint32_t p = 0; p < cpr; ++p) {
             uint32_t ro;
             if (UNIFORM) ro = rr * stride;
-            else if (v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
+            else if (!SORT && v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
             else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
             const uint32_t so = min(ro + GRAN * cc, lim);
             // a chunk may reach past its tile: harmless inside the batch, but the last chunks of the
             // batch's last tile(s) must not leave the caller's buffer -- those few lanes copy their
             // bytes one by one instead
-            const bool inside = v.off + so + GRAN <= batch_end;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inside) == 0, 1)) {
-                dma_piece<true>(src + so, dst + p * (64u * GRAN));
+            const bool inside = all_safe || v.off + so + GRAN <= batch_end;
+            if (__builtin_expect(all_safe || __builtin_amdgcn_ballot_w64(!inside) == 0, 1)) {
+                dma_piece<true, SORT>(src + so, dst + p * (64u * GRAN));
             } else {
                 if (inside) {
-                    dma_piece<true>(src + so, dst + p * (64u * GRAN));
+                    dma_piece<true, SORT>(src + so, dst + p * (64u * GRAN));
                 } else {
                     for (uint32_t j = 0; j < GRAN && v.off + so + j < batch_end; ++j)
                         dst[p * (64u * GRAN) + (uint32_t)lane * GRAN + j] = src[so + j];
@@ -298,16 +345,20 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // wave takes SEG_CHUNK consecutive tiles at a time.  There the tiles are sorted by length, and with single
     // steps every wave met a new length at every tile (its tiles lie `waves` apart) and rebuilt the band matrix
     // each time (set_length: ~150 instructions against ~600 for the tile's scan); a chunk shares one length.
-    const uint64_t SEG_CHUNK = 1ull << a.seg_chunk_shift;
+    // (SORT: one tile at a time -- with chunks of 4 a list's 256 waves have 7 windows open at once, 10 MB, and the XCD's
+    // L2 no longer holds the lines two neighbours share: 1187 against 946 MB fetched per scan of 790 MB)
+    const uint64_t SEG_CHUNK = SORT ? 1ull : 1ull << a.seg_chunk_shift;
     auto next_tile = [&](uint64_t tt) -> uint64_t {
-        if (SEG) return ((tt + 1) & (SEG_CHUNK - 1)) != 0 ? tt + 1 : tt + 1 + (wave_count - 1) * SEG_CHUNK;
+        if (SEG || SORT) return ((tt + 1) & (SEG_CHUNK - 1)) != 0 ? tt + 1 : tt + 1 + (wave_count - 1) * SEG_CHUNK;
         return tt + wave_count;
     };
-    uint64_t t = SEG ? wave_global * SEG_CHUNK : wave_global;
+    uint64_t t = (SEG || SORT) ? wave_global * SEG_CHUNK : wave_global;
     if (t >= n_tiles) return;
 
     // prologue: Q(t) [and S(t)] in flight
-    sk_tile_view cur = probe(t), nxt = cur;
+    sk_tile_view cur = SORT ? sort_finish(sort_issue(t)) : probe(t), nxt = cur;
+    sort_raw raw;
+    raw.e = 0;
     if (SEG) probe_index(cur);
     bool cur_staged = STAGE && cur.rows == 64u;
     if (cur_staged) {
@@ -339,13 +390,24 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const bool active = (uint32_t)lane < cur.rows;
         const int Lv = UNIFORM ? 0 : cur.len; // mixed lengths: this lane's length (0 past the end of the batch)
         bool tile_u = false; // MIXED: this tile's reads have one length (and a window the matrix path takes)
-        if (MIXED) {
+        if (MIXED && SORT) {
+            // one window width w for the tile's reads (lane 0 has one of them): any length with that width builds the band
+            const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
+            const int w0 = l0 / 10 ? l0 / 10 : l0;
+            tile_u = w0 > 0;
+            if (tile_u && w0 != wu) set_length(l0);
+        } else if (MIXED) {
             const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
             tile_u = cur.uni && l0 > 0 && l0 / 10 <= 65;
             if (tile_u && l0 != Lu) set_length(l0);
         }
 
-        if (SEQ_SHARES || RAG) {
+        if (SORT && more) raw = sort_issue(tn);
+        if (SORT) {
+            tile = buf0;
+            if (more) wait_vmcnt(1); // Q(t); the entry load of the next tile stays in flight
+            else wait_vmcnt(0);
+        } else if (SEQ_SHARES || RAG) {
             tile = buf0;
             wait_vmcnt(0); // Q(t)
         } else if (HAS_SEQ) {
@@ -381,7 +443,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             wait_vmcnt(next_pieces); // everything older than Q(t+1) has landed: Q(t), store(t-1)
             parity ^= 1;
         }
-        if (!PROBE_EARLY && more) nxt = probe(tn);
+        if (!PROBE_EARLY && !SORT && more) nxt = probe(tn);
         if (SEG && more) probe_index(nxt);
         if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_team_kernel's
             // tell it that there is work: the word after the error word takes this scan's number (scans of a
@@ -417,9 +479,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const int nwin = (UNIFORM ? scan_u : scanned) ? L - w + 1 : 0;
         const int m = w >> 2, sh = w & 3;
         // one value per wave: known (uniform batch), the lanes' common value (uniform tile of a ragged batch), or reduced
-        const int Lmax = UNIFORM ? L : tile_u ? __builtin_amdgcn_readfirstlane(L) : wave_max(L);
-        const int wmax = UNIFORM ? w : tile_u ? __builtin_amdgcn_readfirstlane(w) : wave_max(w);
-        const int nwinmax = UNIFORM ? nwin : tile_u ? __builtin_amdgcn_readfirstlane(nwin) : wave_max(nwin);
+        const int Lmax = UNIFORM ? L : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(L) : wave_max(L);
+        const int wmax = UNIFORM ? w : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(w) : wave_max(w);
+        const int nwinmax = UNIFORM ? nwin : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(nwin) : wave_max(nwin);
+        // the dwords every scanned read of the tile has in full (SORT: lengths differ by < 10 inside a tile)
+        const int Lfull = SORT ? -wave_max(scanned ? -L : -0x7fffff) : Lmax;
 
         // ---- range check of the whole read in 2 ops per dword: for a char c in [min,max],
         // |c-min| + |c-max| == max-min, and it is larger for every other byte value, so the
@@ -429,7 +493,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         {
             int k = 0;
             if (UNIFORM || tile_u) {
-                const int full = Lmax >> 2; // whole dwords; rows are 8-byte aligned
+                const int full = (SORT ? min(Lfull, Lmax) : Lmax) >> 2; // whole dwords; rows are 8-byte aligned
                 const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
                 for (; k + 8 <= full; k += 8) { // 4 x ds_read_b64 in flight, then 16 SADs
                     uint64_t x[4];
@@ -658,7 +722,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             {
                 int k = 0;
                 if (UNIFORM || tile_u) {
-                    const int full = Lmax >> 2;
+                    const int full = (SORT ? min(Lfull, Lmax) : Lmax) >> 2;
                     const uint64_t *srow64 = reinterpret_cast<const uint64_t *>(srow);
                     for (; k + 8 <= full; k += 8) {
                         uint64_t x[4];
@@ -676,6 +740,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             if (nlo != NONE) three = (int)(nlo >> 3) - 1;
             else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (SORT && more) nxt = sort_finish(raw);
             if (more) {
                 if (SEQ_SHARES) { if (nxt.take) load_tile(qual, buf0, nxt); }   // Q(t+1)
                 else tile_to_lds(seq + nxt.off, buf1, next_bytes, lane);      // S(t+1)
@@ -685,6 +750,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // below and the other waves of the CU cover the DMA latency.  (Staged kernel: only the
             // ragged last tile of the batch takes this way.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (SORT && more) nxt = sort_finish(raw);
             if (more && nxt.take) load_tile(qual, buf0, nxt);
         }
 #if SK_TAIL_PRIO
@@ -721,7 +787,23 @@ sk_scan_tile_any_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restr
                         const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ lengths,
                         sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
 {
+    // a ragged batch that went through the regrouping (sk_sort.hip) and turned out mixed, without reads too long for
+    // the tiles, is the sorted scan's (enqueued right behind; it asks the opposite question)
+    if (!UNIFORM && a.sort_flags && scalar_load(a.sort_flags) != 0 && scalar_load(a.sort_flags + 1) == 0) return;
     sk_scan_tile_body<UNIFORM, HAS_SEQ, MFMA, 1, 0, false, 0, true>(qual, seq, lengths, out, errword, a, nullptr, nullptr, offsets);
+}
+
+// the tiles of a regrouped ragged batch (sk_sort.hip): lists = 8 tile lists of a.n_tiles entries, counts = their lengths
+template <bool HAS_SEQ>
+__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
+sk_scan_tile_sorted_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                           const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ perm,
+                           const unsigned long long *__restrict__ lists, const uint32_t *__restrict__ counts,
+                           sk_cut_dev *__restrict__ out, unsigned long long *errword, sk_scan_args a)
+{
+    if (scalar_load(a.sort_flags) == 0 || scalar_load(a.sort_flags + 1) != 0) return; // a uniform batch, or one with long reads
+    sk_scan_tile_body<false, HAS_SEQ, true, 1, 0, false, 0, true, true>(qual, seq, counts, out, errword, a, reinterpret_cast<const sk_tile_dev *>(lists),
+                                                                         reinterpret_cast<const uint32_t *>(perm), offsets);
 }
 
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
@@ -924,6 +1006,29 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     if (mfma) return launch(sk_scan_tile_any_kernel<true, false, true>);
     if (uniform) return launch(sk_scan_tile_any_kernel<true, false, false>);
     return launch(sk_scan_tile_any_kernel<false, false, true>);
+}
+
+// The sorted scan of a regrouped ragged batch.  a->buf_bytes = LDS bytes of a wave (sized for the longest read the
+// tiles take), a->n_tiles = entries per tile list, a->sort_flags = the sort's verdict (device).
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sorted(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets, const uint64_t *perm,
+                                       const unsigned long long *lists, const uint32_t *counts, sk_cut_dev *out,
+                                       unsigned long long *errword, const sk_scan_args *a, int cu_count, hipStream_t stream)
+{
+    const uint32_t lds_bytes = a->buf_bytes;
+    if (lds_bytes == 0 || lds_bytes > SK_LDS_PER_CU) return hipErrorInvalidValue;
+    int per_cu = (int)(SK_LDS_PER_CU / lds_bytes);
+    if (per_cu > 16) per_cu = 16;
+    uint64_t grid = ((uint64_t)cu_count * per_cu) & ~7ull; // the same number of workgroups for every list
+    const uint64_t most = ((a->n_reads + 63) >> 6) + 8;
+    if (grid > most) grid = (most + 7) & ~7ull;
+    if (grid < 8) grid = 8;
+    auto launch = [&](auto kern) {
+        const kernel_facts facts = prepare_kernel(kern);
+        if (facts.status != hipSuccess) return facts.status;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, perm, lists, counts, out, errword, *a);
+        return hipGetLastError();
+    };
+    return a->truncn ? launch(sk_scan_tile_sorted_kernel<true>) : launch(sk_scan_tile_sorted_kernel<false>);
 }
 
 // diagnostic: the uniform, no-seq tile kernel with part of its work removed (tools/ablate.py).
