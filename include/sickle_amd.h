@@ -23,7 +23,14 @@
  *   ragged      : offsets != NULL; read r = bytes [offsets[r], offsets[r+1]) of qual (and seq),
  *                 offsets ascending.  batch->stride is then a HINT: the longest read of the batch
  *                 (0 = unknown), which sizes the kernel's LDS tiles (sk_submit / sk_trim_batch see
- *                 the offsets and work it out themselves).  Tiles of 64 consecutive reads are
+ *                 the offsets and work it out themselves).  (ABI 1 ignored `stride` on such batches: a
+ *                 caller that leaves a stale value there gets the right cuts from a slower kernel --
+ *                 above 4096 the batch goes to the long-read kernel whole.  Set it to 0 or to the truth.)
+ *                 A batch of 65 536 reads or more whose reads differ in length is regrouped on the
+ *                 device first (windows of 8192 reads counting-sorted by window width, ~9 bytes of
+ *                 scratch per read owned by the context, per stream): its tiles then hold reads of one
+ *                 window width and take the matrix path; batches of one length and batches with reads
+ *                 too long for a tile are scanned as they lie.  Cuts and errors keep the caller's numbering.  Tiles of 64 consecutive reads are
  *                 re-strided on their way into LDS and scanned one lane per read; a tile whose
  *                 reads are too long for that goes to the general kernel (a wave per read, the read
  *                 streamed through LDS: any length).  A hint beyond 4096 declares a long-read batch:
@@ -72,6 +79,10 @@ enum {
 };
 
 #define SK_TILE_MAX_STRIDE 512u /* two LDS buffers of 64 reads per wave must fit the 160 KiB of a CU */
+/* The longest read a batch may hold: 16 Mi bases (sk_err and the device's error word keep 24 bits of position).  The
+ * reference has no such limit (it has no limits at all: std::string).  sk_submit / sk_trim_batch return SK_EINVAL for
+ * an `offsets` batch with a longer read, and so does a fixed-stride batch with read_len beyond it; the CLI names the
+ * record and exits 1. */
 #define SK_MAX_READ_LEN (1u << 24)
 
 /* the config ints of Abstract_Trimmer, reference src/trim.h:16-20 */

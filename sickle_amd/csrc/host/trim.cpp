@@ -617,6 +617,14 @@ void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
     sk_params p = {qualtype, qual_threshold, length_threshold, no_fiveprime, trunc_n};
     const int rc = sk_submit(ctx, dev_slot, &p, &b, s.cuts);
     if (rc != SK_OK) {
+        // the one limit the reference does not have: a read beyond SK_MAX_READ_LEN (16 Mi bases; the device's error
+        // word keeps 24 bits of position) -- say so, with the record, instead of the general message
+        for (size_t i = 0; i < n; ++i)
+            if (reads[i].qual.length() > SK_MAX_READ_LEN) {
+                fprintf(stderr, "****Error: record '%.*s' has %zu bases; this build scans reads of up to %u bases.\n\n",
+                        (int)std::min<size_t>(reads[i].name.length(), 200), reads[i].name.data(), reads[i].qual.length(), SK_MAX_READ_LEN);
+                fatal_exit(EXIT_FAILURE);
+            }
         fprintf(stderr, "****Error: device scan could not be started (%d): %s\n\n", rc, sk_last_error(ctx));
         fatal_exit(EXIT_FAILURE);
     }

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # the trace + stats pass runs the SAME command as the plain bench (default steps/warmup, CPU baseline
 # included); the counter passes only need a few launches
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-e2e $* > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 $*"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 --settle 20 $*"
 echo "trace done"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -21,5 +21,5 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   echo "pmc $i done"
 done
 # keep only the CSVs that matter small
-find "$OUT" -name "*.csv" -size +8M -delete
+find "$OUT" -name "*.csv" -size +200M -delete
 ls -R "$OUT" | head -50

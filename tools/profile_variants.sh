@@ -18,6 +18,6 @@ for V in $VARIANTS; do
     i=$((i+1))
     rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 $ROOT/bench.py --variant $V --steps 5 > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err" || { echo "$V: pmc pass $i failed"; tail -3 "$OUT/pmc$i.err"; }
   done
-  find "$OUT" -name "*.csv" -size +8M -delete
+  find "$OUT" -name "*.csv" -size +16M -delete
   echo "$V done: $(cat $OUT/trace_bench.json | tail -1 | cut -c1-200)"
 done
