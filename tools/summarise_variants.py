@@ -25,7 +25,7 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
            "algorithmic_bytes_per_launch": line["algorithmic_bytes_per_launch"], "algorithmic_GBps_by_events": line["achieved"]}
     if stats:
         shutil.copyfile(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % v))
-        rows = [r for r in csv.DictReader(open(stats[0])) if "sk_scan" in r["Name"]]
+        rows = [r for r in csv.DictReader(open(stats[0])) if "sk_scan" in r["Name"] or "sk_sort" in r["Name"]]
         ent["trace"] = [{"name": r["Name"][:100], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in rows]
         tot = sum(float(r["AverageNs"]) * int(r["Calls"]) for r in rows)
         # a variant may take two kernels per scan (ragged: tile + general): time per scan = total / scans
@@ -45,7 +45,7 @@ for vdir in sorted(glob.glob(os.path.join(src, "*/"))):
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for row in csv.DictReader(open(f[0])):
-            if "sk_scan" in row["Kernel_Name"]:  # every kernel of the scan (a ragged scan launches two)
+            if "sk_scan" in row["Kernel_Name"] or "sk_sort" in row["Kernel_Name"]:  # every kernel of the scan (a ragged scan launches several)
                 agg[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
         for k, per in agg.items():
             counters[k] = {"dispatches": len(per), "scans": nscans, "per_scan": sum(per.values()) / nscans}

@@ -145,8 +145,8 @@ def build(name, torch, capi, ctx, dev, stream, bench):
         q = _quals(torch, (tot,), dev, 33)
         out = torch.empty((n, 2), dtype=torch.int32, device=dev)
         keep.extend([q, off, out])
-        kern = "sk_scan_stream_kernel" if name == "long" else "sk_scan_tile_any_kernel"
-        what = {"ragged150": "ragged offsets, every read 150 bp", "ragged_mix": "ragged offsets, U{75..301} bp in input order",
+        kern = "sk_scan_stream_kernel" if name == "long" else "sk_scan_tile_sorted_kernel" if name == "ragged_mix" else "sk_scan_tile_any_kernel"
+        what = {"ragged150": "ragged offsets, every read 150 bp", "ragged_mix": "ragged offsets, U{75..301} bp in input order (regrouped on the device: sort + sorted scan)",
                 "long": "ragged offsets, U{1000..30000} bp"}[name]
         return dict(launch=lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, offsets_ptr=off.data_ptr(), stride=hint,
                                                          stream=sp),
