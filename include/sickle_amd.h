@@ -212,11 +212,13 @@ int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
- * 7 = general, medium reads (a wave per read up to a longest read of 4096, the read resident in LDS, window sums
- * from the matrix pipe), 6 = general, long reads (a wave per read with the read streamed through LDS), 3 = tiled
- * over a segmented batch, 4 = tiled with the tile staged through registers (equal lengths, no sequence buffer, row
- * stride 72..160), 5 = tiled with rows re-strided on the way into LDS (packed / misaligned fixed stride, ragged).
- * (2 = round 2's teams of 16 lanes per read: no shape selects it any more.)  For tests and bench labels. */
+ * 2 = general, medium reads (teams of 16 lanes per read, up to a longest read of 4096), 6 = general, long reads (a
+ * wave per read with the read streamed through LDS), 3 = tiled over a segmented batch, 4 = tiled with the tile
+ * staged through registers (equal lengths, no sequence buffer, row stride 72..160), 5 = tiled with rows re-strided
+ * on the way into LDS (packed / misaligned fixed stride, ragged; a ragged batch of mixed lengths is regrouped on
+ * the device first -- the device decides, so the answer stays 5).  7 = round 3's matrix-pipe wave-per-read kernel
+ * for medium reads (sk_band.hip): built and parity-tested, no shape selects it (SK_GENERAL=band forces it; it is
+ * not faster than 2).  For tests and bench labels. */
 int sk_kernel_for(const sk_batch *batch);
 
 /* For bench.py's roofline: name of the dominant kernel as rocprofv3 reports it */
