@@ -77,6 +77,7 @@ struct sk_ctx {
     int device = 0;
     int cu_count = 256;
     hipStream_t compute = nullptr, copy = nullptr;
+    uint32_t *d_band = nullptr;          // the band matrices of every window width the tile kernels take (sk_device.h)
     unsigned long long *d_err = nullptr; // error word of the device-resident path on the NULL stream
     unsigned long long *h_err = nullptr;
     // ... and one per other stream the caller scans on: errors of scans enqueued on different streams do
@@ -181,9 +182,10 @@ int make_args(sk_ctx *ctx, const sk_params *p, const sk_batch *b, sk_scan_args *
     a->stream_nb = 0;
     a->stream_read_cost = 0;
     a->stream_tbl = 0;
-    static const uint32_t seg_shift = [] { const char *e = getenv("SK_SEG_CHUNK_SHIFT"); return e ? (uint32_t)atoi(e) : 2u; }();
+    static const uint32_t seg_shift = [] { const char *e = getenv("SK_SEG_CHUNK_SHIFT"); return e ? (uint32_t)atoi(e) : 0u; }();
     a->seg_chunk_shift = seg_shift > 6u ? 6u : seg_shift;
     a->sort_flags = nullptr;
+    a->band_table = ctx ? ctx->d_band : nullptr;
     return SK_OK;
 }
 
@@ -467,6 +469,16 @@ int sk_create(int device, int slots, sk_ctx **out)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SK_TRY(hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     SK_TRY(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    {
+        std::vector<uint32_t> band(SK_BAND_TABLE_DWORDS);
+        for (uint32_t w = 0; w < SK_BAND_WIDTHS; ++w)
+            for (int b = 0; b < 3; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        band[((w * 3u + (uint32_t)b) * 64u + (uint32_t)lane) * 4u + (uint32_t)j] = sk_band_dword(lane, (int)w, 16 * (lane >> 5) + 4 * j + 32 * b);
+        SK_TRY(hipMalloc(&ctx->d_band, band.size() * sizeof(uint32_t)));
+        SK_TRY(hipMemcpy(ctx->d_band, band.data(), band.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     SK_TRY(hipMalloc(&ctx->d_err, 8 * sizeof(unsigned long long)));
     SK_TRY(hipMemset(ctx->d_err, 0xff, sizeof(unsigned long long)));
     SK_TRY(hipMemset(ctx->d_err + 1, 0, 7 * sizeof(unsigned long long))); // the hand-over word (see enqueue_scan), four pair counters, tiles left by the tile kernel
@@ -506,6 +518,7 @@ void sk_destroy(sk_ctx *ctx)
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.finished) (void)hipEventDestroy(s.finished);
     }
+    if (ctx->d_band) (void)hipFree(ctx->d_band);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
     for (auto &kv : ctx->stream_err) {

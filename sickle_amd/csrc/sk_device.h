@@ -56,9 +56,33 @@ struct sk_scan_args {
     uint32_t stream_read_cost;  // streaming general kernel: what a read costs beyond its bytes when the batch is cut into spans
     uint32_t stream_tbl;  // streaming general kernel: entries of the prefix table (a power of two)
     uint32_t seg_chunk_shift; // segmented batches: a wave takes 1 << this consecutive tiles at a time
+    const uint32_t *band_table; // SK_BAND_WIDTHS band matrices, one per window width (sk_band_dword): what a tile kernel loads when a
+                                // tile's window width differs from the one before (segmented batches, regrouped ragged batches)
     const uint32_t *sort_flags; // ragged batches behind the device-side regrouping: {windows of mixed lengths, reads too long for the tiles}; the
                                 // plain tile kernel (and the general kernel behind it) return at once when the sorted scan runs, and vice versa
 };
+
+// The band matrix of window width wu, as lane `lane` of a wave holds it for v_mfma_i32_32x32x32_i8 (sk_kernels.hip, MFMA path):
+// the dword whose four bytes multiply positions p .. p+3 (relative to a 32-position block), 1 where the lane's window
+// covers the position.  The lane supplies row m' = lane & 31 of A; the hardware puts that row into accumulator r of lane
+// half hh with m' = (r & 3) + 8 * (r >> 2) + 4 * hh, and that slot is to be window 16 * hh + r.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+static inline uint32_t sk_band_dword(int lane, int wu, int p)
+{
+    const int mp = lane & 31;
+    const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
+    const int win = 16 * hh + r;
+    const int hi = win + wu - p, lo = win - p; // bytes j with lo <= j < hi
+    const uint32_t below_hi = hi >= 4 ? 0x01010101u : (hi <= 0 ? 0u : 0x01010101u & ((1u << (8 * hi)) - 1u));
+    const uint32_t below_lo = lo >= 4 ? 0x01010101u : (lo <= 0 ? 0u : 0x01010101u & ((1u << (8 * lo)) - 1u));
+    return below_hi & ~below_lo;
+}
+// the table: [width 0 .. SK_BAND_WIDTHS-1][block 0..2][lane 0..63][4 dwords]: dword j of block b of a lane = positions
+// 16 * (lane >> 5) + 4 * j + 32 * b
+#define SK_BAND_WIDTHS 66u
+#define SK_BAND_TABLE_DWORDS (SK_BAND_WIDTHS * 3u * 64u * 4u)
 
 // internal to libsickle_amd.so (not part of the C ABI)
 extern "C" __attribute__((visibility("hidden"))) int sk_tile_is_staged(uint32_t stride, uint32_t read_len, int has_seq);

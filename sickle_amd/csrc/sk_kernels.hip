@@ -46,8 +46,8 @@
 // to stay outstanding.  With -n the sequence tile of the same reads rides the same two
 // buffers: Q(t) -> buf0, S(t) -> buf1, Q(t+1) -> buf0, ...
 // ------------------------------------------------------------------------------------------
-#define SK_STAGE_MIN 5  /* register-staged kernels exist for tiles of 5..10 KiB: row strides 72..160 */
-#define SK_STAGE_MAX 10
+#define SK_STAGE_MIN 5  /* register-staged kernels exist for tiles of 5..20 KiB: row strides 72..320 */
+#define SK_STAGE_MAX 20
 
 // MFMA = true (uniform-length batches; w <= 65, i.e. every uniform length the tiled kernel takes):
 // the window sums are taken off the vector ALU.  A box filter is a banded 0/1 matrix, so for 32 windows x 32 reads
@@ -110,7 +110,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // every tile of the usual fixed-length run handed over as offsets -- takes the matrix path and the
     // uniform row walks; the other tiles walk the vector-ALU path.  Decided per tile, wave-uniformly.
     constexpr bool MIXED = MFMA && !UNIFORM;
-    static_assert(STAGE == 0 || (UNIFORM && !HAS_SEQ && NBUF == 1 && !SEG), "register staging: uniform batches, one buffer");
+    static_assert(STAGE == 0 || (UNIFORM && !HAS_SEQ && NBUF == 1 && (SEG == 0 || SEG == 2)), "register staging: uniform tiles, one buffer");
     static_assert(!SEG || (UNIFORM && MFMA && NBUF == 1), "segmented batches run the uniform matrix path, one buffer");
     // -n: NBUF == 2 keeps the quality and the sequence tile in two buffers (8 waves per CU);
     // NBUF == 1 runs both through ONE buffer, one after the other (16 waves per CU)
@@ -154,37 +154,37 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     sk_v4i bandA0 = {0, 0, 0, 0}, bandA1 = {0, 0, 0, 0}, bandA2 = {0, 0, 0, 0};
     sk_v16i negT;
     const int half = lane >> 5;
-    auto set_length = [&](int len) {
+    // TABLE (segmented batches, regrouped ragged batches: the window width changes from tile to tile): the band matrix
+    // is not computed (~150 vector instructions) but LOADED from the context's table of all widths (three 16-byte
+    // loads per lane, from L2) -- a tile ahead, into `band_next`, while the tile before is scanned; installed at the top
+    // of the turn that needs it.  Invariant: whenever a turn's width differs from wu, band_next holds that width's band.
+    constexpr bool TABLE = SEG != 0 || SORT;
+    struct band3 {
+        sk_v4i b0, b1, b2;
+    };
+    band3 band_next{{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto band_fetch = [&](int w) -> band3 {
+        typedef const __attribute__((address_space(1))) sk_v4i *gv4;
+        gv4 tb = (gv4)(uintptr_t)a.band_table + ((uint32_t)w * 3u * 64u + (uint32_t)lane);
+        band3 b;
+        b.b0 = tb[0];
+        b.b1 = tb[64];
+        b.b2 = (SEG == 2) ? b.b1 : tb[128]; // (SEG == 2: no window reaches into a third block)
+        return b;
+    };
+    auto width_of = [](int len) -> int { return len / 10 ? len / 10 : len; }; // trim.cpp:8,30
+    // the scalars of a length; the threshold vector when the width changed
+    auto set_scalars = [&](int len) {
+        const int w_old = wu;
         Lu = len;
         scan_u = Lu > 0 && Lu >= a.lthr;  // reference trim.cpp:21
-        wu = Lu / 10 ? Lu / 10 : Lu;      // trim.cpp:8,30
+        wu = width_of(Lu);
         // windows wider than 33 reach into a third 32-position block (never in the staged kernels: rows
-        // <= 160 bytes).  Segmented launches fix it at compile time (SEG = 2: every tile of the launch
+        // <= 320 bytes).  Segmented launches fix it at compile time (SEG = 2: every tile of the launch
         // has w <= 33; SEG = 3: three blocks for every tile, right for any w <= 65): one MFMA loop
         // instead of two in the kernel, fewer registers
         three_blocks = MFMA && STAGE == 0 && (SEG == 2 ? false : SEG == 3 ? true : wu > 33);
-        if (MFMA) {
-            // ---- constants of the matrix path.  This lane supplies row m' = lane&31 of A; the
-            // hardware puts row m' into accumulator reg r of lane half hh with
-            // m' = (r&3) + 8*(r>>2) + 4*hh; we want that slot to be window 16*hh + r
-            int mp = lane & 31;
-            // segmented batches call this inside the tile loop: without the barrier the compiler hoists
-            // the 48 per-byte position constants out of the loop and pins a register to each
-            if (SEG || MIXED) asm volatile("" : "+v"(mp));
-            const int hh = (mp >> 2) & 1, r = (mp & 3) | ((mp >> 3) << 2);
-            const int win = 16 * hh + r;
-            // band bytes of positions p .. p+3 (relative to 32*b): 1 where win <= position < win + wu
-            auto ones_below = [](int n) -> uint32_t { // 0x01 in the bytes j < n of a dword
-                return n >= 4 ? 0x01010101u : (n <= 0 ? 0u : 0x01010101u & ((1u << (8 * n)) - 1u));
-            };
-            auto band4 = [&](int p) -> int { return (int)(ones_below(win + wu - p) & ~ones_below(win - p)); };
-            const int k0 = (lane >> 5) * 16; // the first position (relative to 32*b) this lane's bytes multiply
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bandA0[j] = band4(k0 + 4 * j);
-                bandA1[j] = band4(k0 + 4 * j + 32);
-                bandA2[j] = band4(k0 + 4 * j + 64);
-            }
+        if (MFMA && (!TABLE || wu != w_old)) {
             const int T = a.craw * wu;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -196,16 +196,62 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             }
         }
     };
-    if (!SEG) set_length((int)a.read_len);
+    auto install_band = [&](const band3 &b) {
+        bandA0 = b.b0;
+        bandA1 = b.b1;
+        bandA2 = b.b2;
+    };
+    auto set_length = [&](int len) {
+        set_scalars(len);
+        if (MFMA) {
+            // ---- constants of the matrix path, computed (uniform batches: once per launch; ragged batches in input
+            // order: at the rare change of length): sk_band_dword says which byte is which
+            int ln = lane;
+            // inside the tile loop: without the barrier the compiler hoists the 48 per-byte position constants out
+            // of the loop and pins a register to each
+            if (MIXED) asm volatile("" : "+v"(ln));
+            const int k0 = (ln >> 5) * 16; // the first position (relative to 32*b) this lane's bytes multiply
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bandA0[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j);
+                bandA1[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + 32);
+                bandA2[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + 64);
+            }
+        }
+    };
+    if (!TABLE) set_length((int)a.read_len);
 
     const uint64_t batch_end = RAG ? rag_batch_end(offsets, lengths, a) : 0;
-    auto probe = [&](uint64_t tt) -> sk_tile_view {
+    // (segmented batches: the descriptor of a tile is loaded TWO turns ahead, and by a VECTOR load -- every lane the
+    // same address, the values back into scalar registers a turn later.  A scalar load shares its counter with the LDS
+    // reads of the scan, so wherever it is issued the next wait for an LDS read waits for it as well, and a
+    // descriptor that comes from HBM costs the wave ~1 us per tile: 5-8 % measured against the uniform kernel on the
+    // same data.  The vector load goes out once the turn's tile has landed and is collected, in order, by the next
+    // turn's wait for its tile.)
+    auto fetch_desc = [&](uint64_t tt) -> sk_tile_dev {
+        uint32_t at = (uint32_t)tt * (uint32_t)sizeof(sk_tile_dev); // (< 2^26 tiles: n_reads < 2^32)
+        asm volatile("" : "+v"(at)); // a vector offset: global_load, counted by vmcnt
+        return *reinterpret_cast<const sk_tile_dev *>(reinterpret_cast<const uint8_t *>(tiles) + at);
+    };
+    auto uniform_desc = [&](const sk_tile_dev &d) -> sk_tile_dev {
+        sk_tile_dev u;
+        u.byte_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d.byte_off >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)d.byte_off);
+        u.slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.slot0);
+        u.stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.stride);
+        const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)d.rows | ((uint32_t)d.read_len << 16)));
+        u.rows = (uint16_t)rl;
+        u.read_len = (uint16_t)(rl >> 16);
+        u.reserved = 0;
+        return u;
+    };
+    auto probe = [&](uint64_t tt, const sk_tile_dev *ahead = nullptr) -> sk_tile_view {
         sk_tile_view v;
         v.take = true;
         v.uni = false;
         v.rowoff = 0;
         if (SEG) {
-            const sk_tile_dev d = tiles[tt];
+            const sk_tile_dev d = ahead ? uniform_desc(*ahead) : tiles[tt];
             v.off = d.byte_off;
             v.ts = d.stride;
             v.rows = d.rows;
@@ -276,13 +322,20 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         return v;
     };
 
-    // segmented batches scatter their cuts back to the caller's read order.  The descriptor is a scalar
-    // load (not counted by vmcnt: it can be issued before the wait for the tile); the index is a vector
-    // load that needs the descriptor, issued after that wait, when the descriptor has long arrived
-    auto probe_index = [&](sk_tile_view &v) {
-        const uint32_t slot = (uint32_t)v.r + min((uint32_t)lane, v.rows - 1u);
-        v.r = a.slot_order ? (uint64_t)slot : (uint64_t)out_index[slot]; // slot order: one coalesced stream of cuts
+    // segmented batches: a tile's descriptor is a scalar load (not counted by vmcnt: it can be issued before the
+    // wait for the tile); v.r becomes this lane's slot.  Cuts go out in slot order (one coalesced stream), or are
+    // scattered back to the caller's read order through out_index: that index is a vector load issued once the tile
+    // has landed and collected when the scan is over, just before the refill goes out -- the scan covers its latency.
+    // (It is an asm load because the compiler, given the choice, waits for it on the spot: 3.45 against 4.2 TB/s.)
+    auto probe_index = [&](sk_tile_view &v) { v.r = (uint64_t)((uint32_t)v.r + min((uint32_t)lane, v.rows - 1u)); };
+    const bool scatter = SEG && !a.slot_order;
+    auto index_issue = [&](uint64_t slot) -> uint32_t {
+        uint32_t idx;
+        const uint32_t *src = out_index + slot;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(idx) : "v"(src) : "memory");
+        return idx;
     };
+    auto index_settle = [&](uint32_t &idx) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx)::"memory"); };
 
     // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, chunks per row)
     // comes from the row's start + c chunks.  Chunks beyond a row's end fetch what follows it in the batch (nobody
@@ -297,12 +350,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const uint32_t lim = (v.bytes ? v.bytes : 1u) - 1u;
         // (a tile whose last byte is followed by 16 more of the batch: no chunk of it can leave the caller's buffer)
         const bool all_safe = v.off + (uint64_t)lim + 1u + GRAN <= batch_end; // wave-uniform
-        for (uint32_t p = 0; p < cpr; ++p) {
-            uint32_t ro;
-            if (UNIFORM) ro = rr * stride;
-            else if (!SORT && v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
-            else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
-            const uint32_t so = min(ro + GRAN * cc, lim);
+        // one piece: its chunks start `ro` bytes into the tile (a row start per lane) + GRAN * cc
+        auto piece = [&](uint32_t p, uint32_t ro, uint32_t cc_p) {
+            const uint32_t so = min(ro + GRAN * cc_p, lim);
             // a chunk may reach past its tile: harmless inside the batch, but the last chunks of the
             // batch's last tile(s) must not leave the caller's buffer -- those few lanes copy their
             // bytes one by one instead
@@ -317,11 +367,39 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                         dst[p * (64u * GRAN) + (uint32_t)lane * GRAN + j] = src[so + j];
                 }
             }
+        };
+        auto advance = [&]() {
             cc += rd;
             rr += qd;
             if (cc >= cpr) {
                 cc -= cpr;
                 ++rr;
+            }
+        };
+        if (SORT) {
+            // a row start per lane, fetched from the lane that holds the row: FOUR pieces' worth of ds_bpermute go out
+            // before the first is waited for (one at a time, each piece sat out the LDS round trip: 19 of them for a
+            // 301-base tile)
+            for (uint32_t p = 0; p < cpr; p += 4) {
+                uint32_t ro[4], cq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ro[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(rr, 63u) << 2), (int)v.rowoff);
+                    cq[u] = cc;
+                    advance();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p + (uint32_t)u < cpr) piece(p + (uint32_t)u, ro[u], cq[u]);
+            }
+        } else {
+            for (uint32_t p = 0; p < cpr; ++p) {
+                uint32_t ro;
+                if (UNIFORM) ro = rr * stride;
+                else if (v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
+                else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
+                piece(p, ro, cc);
+                advance();
             }
         }
     };
@@ -334,11 +412,14 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // 16 bytes per lane at p KiB; STAGE = the number of pieces, the last one may be a half (its
     // upper lanes repeat the tile's last 16 bytes: same data to the same place, no predication).
     // The last tile of a batch, if it is not full, comes in by LDS-DMA like in the unstaged kernel.
+    // Segmented batches (SEG): STAGE is the most a tile of the launch needs; the pieces past a tile's end repeat its
+    // last 16 bytes like the half piece above (no branches: with them the compiler no longer counts its waits and every
+    // write waits for the loads just issued -- 2.4 against 4.8 TB/s); tiles with fewer than 64 rows come in by LDS-DMA.
     sk_v4u stage[STAGE ? STAGE : 1];
     const uint32_t full_bytes = 64u * stride;
-    auto stage_off = [&](int p) -> uint32_t {
+    auto stage_off = [&](int p, uint32_t bytes) -> uint32_t {
         const uint32_t off = (uint32_t)p * 1024u + (uint32_t)lane * 16u;
-        return p == STAGE - 1 ? min(off, full_bytes - 16u) : off;
+        return (SEG || p == STAGE - 1) ? min(off, bytes - 16u) : off;
     };
 
     // Which tiles a wave takes: tile t, then t + (number of waves), ... -- except in segmented batches, where a
@@ -357,14 +438,16 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 
     // prologue: Q(t) [and S(t)] in flight
     sk_tile_view cur = SORT ? sort_finish(sort_issue(t)) : probe(t), nxt = cur;
+    if (TABLE) band_next = band_fetch(width_of(__builtin_amdgcn_readfirstlane(cur.len))); // (wu == 0: the first turn installs it)
     sort_raw raw;
     raw.e = 0;
     if (SEG) probe_index(cur);
     bool cur_staged = STAGE && cur.rows == 64u;
     if (cur_staged) {
+        const uint32_t cb = SEG ? cur.bytes : full_bytes;
 #pragma unroll
         for (int p = 0; p < STAGE; ++p)
-            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + cur.off + stage_off(p)));
+            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + cur.off + stage_off(p, cb)));
     } else if (cur.take) {
         load_tile(qual, buf0, cur);
     }
@@ -375,14 +458,19 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // vmcnt(0), and a load issued just before it would put its whole latency on every tile
     constexpr bool PROBE_EARLY = NBUF == 2 || STAGE != 0 || ABLATE != 0 || SEG != 0;
 
+    sk_tile_dev ahead{};
+    if (SEG) ahead = fetch_desc(min(next_tile(t), n_tiles - 1));
     for (; t < n_tiles; t = next_tile(t)) {
         const uint64_t tn = next_tile(t);
         const bool more = tn < n_tiles;
-        if (PROBE_EARLY && more) nxt = probe(tn);
+        if (PROBE_EARLY && more) nxt = probe(tn, SEG ? &ahead : nullptr);
         const uint32_t ts = cur.ts;  // this tile's row pitch in LDS
         const uint64_t r = cur.r;
         const uint32_t cur_bytes = cur.bytes;
-        if (SEG && cur.len != Lu) set_length(cur.len);
+        if (SEG && cur.len != Lu) {
+            if (width_of(cur.len) != wu) install_band(band_next);
+            set_scalars(cur.len);
+        }
         const uint32_t next_bytes = (PROBE_EARLY && more) ? nxt.bytes : 0u;
         const int next_pieces = (PROBE_EARLY && more) ? tile_pieces(next_bytes) : 0;
         const uint8_t *tile;
@@ -395,17 +483,28 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
             const int w0 = l0 / 10 ? l0 / 10 : l0;
             tile_u = w0 > 0;
-            if (tile_u && w0 != wu) set_length(l0);
+            if (tile_u && w0 != wu) {
+                install_band(band_next);
+                set_scalars(l0);
+            }
         } else if (MIXED) {
             const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
             tile_u = cur.uni && l0 > 0 && l0 / 10 <= 65;
             if (tile_u && l0 != Lu) set_length(l0);
         }
 
-        if (SORT && more) raw = sort_issue(tn);
+        int band_loads = 0; // SORT: vector loads issued at the top of this turn behind the entry load
+        if (SORT && more) {
+            raw = sort_issue(tn);
+            const int wn = (int)(raw.d0[1] >> 24); // the next tile's window width (its class; 0: empty reads, no band)
+            if (wn != wu && wn != 0) {
+                band_next = band_fetch(wn);
+                band_loads = 3;
+            }
+        }
         if (SORT) {
             tile = buf0;
-            if (more) wait_vmcnt(1); // Q(t); the entry load of the next tile stays in flight
+            if (more) wait_vmcnt(1 + band_loads); // Q(t); the entry load of the next tile (and its band) stay in flight
             else wait_vmcnt(0);
         } else if (SEQ_SHARES || RAG) {
             tile = buf0;
@@ -417,7 +516,33 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         } else if (STAGE) {
             tile = buf0;
             const bool next_staged = more && nxt.rows == 64u && ABLATE != 2;
-            if (cur_staged && (ABLATE != 2 || t == wave_global)) {
+            if (SEG) {
+                // all the writes, then all the loads: with the branches in between the compiler no longer counts its
+                // waits, and a piece's write would wait for the loads just issued (measured: 2.4 against 4.8 TB/s).
+                // A tile of fewer than 64 rows (the last of its length) came in by LDS-DMA; the tile after it may
+                // be a staged one again.
+                if (cur_staged && next_staged) {
+                    const uint8_t *nsrc = qual + nxt.off;
+#pragma unroll
+                    for (int p = 0; p < STAGE; ++p) {
+                        *reinterpret_cast<sk_v4u *>(buf0 + stage_off(p, cur_bytes)) = stage[p];
+                        stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + stage_off(p, next_bytes)));
+                    }
+                } else {
+                    if (cur_staged) {
+#pragma unroll
+                        for (int p = 0; p < STAGE; ++p) *reinterpret_cast<sk_v4u *>(buf0 + stage_off(p, cur_bytes)) = stage[p];
+                    } else {
+                        wait_vmcnt(0);
+                    }
+                    if (next_staged) {
+                        const uint8_t *nsrc = qual + nxt.off;
+#pragma unroll
+                        for (int p = 0; p < STAGE; ++p)
+                            stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + stage_off(p, next_bytes)));
+                    }
+                }
+            } else if (cur_staged && (ABLATE != 2 || t == wave_global)) {
                 // piece by piece: into the LDS buffer, and the register is reloaded at once with the
                 // same piece of the next tile (of the first KiB of this tile again if there is no full
                 // next tile: loads nobody uses keep the code free of branches and its wait counts exact)
@@ -425,7 +550,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 const uint32_t keep = next_staged ? ~0u : 1023u; // no next tile: every piece re-reads the first KiB
 #pragma unroll
                 for (int p = 0; p < STAGE; ++p) {
-                    const uint32_t off = stage_off(p);
+                    const uint32_t off = stage_off(p, full_bytes);
                     *reinterpret_cast<sk_v4u *>(buf0 + off) = stage[p];
                     stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(nsrc + (off & keep)));
                 }
@@ -444,7 +569,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             parity ^= 1;
         }
         if (!PROBE_EARLY && !SORT && more) nxt = probe(tn);
+        if (SEG) ahead = fetch_desc(min(next_tile(tn), n_tiles - 1));
         if (SEG && more) probe_index(nxt);
+        if (SEG && more && width_of(nxt.len) != wu) band_next = band_fetch(width_of(nxt.len));
+        uint32_t oidx = 0;
+        if (scatter) oidx = index_issue(r);
         if (RAG && !cur.take) { // nothing was loaded: this tile is sk_scan_team_kernel's
             // tell it that there is work: the word after the error word takes this scan's number (scans of a
             // stream are ordered and numbered upwards, so the word never needs a reset)
@@ -688,8 +817,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     uint32_t f = keep_first(bad_flags(row[k], min4, hi4), L - 4 * k);
                     if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
                 }
-                // (segmented batches in slot order: the caller's read number comes from out_index here only)
-                if (p < touched) report_error(errword, (SEG && a.slot_order) ? (uint64_t)out_index[r] : r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
+                // (segmented batches: r is the slot; the caller's read number is out_index[slot])
+                if (p < touched) report_error(errword, SEG ? (uint64_t)out_index[r] : r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
             }
         }
 
@@ -700,6 +829,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 // the quality scan is over: the same buffer now takes the sequence tile of these reads
                 load_tile(seq, buf0, cur);
                 wait_vmcnt(0);
+                if (scatter) index_settle(oidx);
             } else {
                 // buf0 is free now: start Q(t+1), then retire S(t)
                 if (more) tile_to_lds(qual + nxt.off, buf0, next_bytes, lane);
@@ -750,6 +880,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // below and the other waves of the CU cover the DMA latency.  (Staged kernel: only the
             // ragged last tile of the batch takes this way.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (scatter) index_settle(oidx);
             if (SORT && more) nxt = sort_finish(raw);
             if (more && nxt.take) load_tile(qual, buf0, nxt);
         }
@@ -762,7 +893,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             five = -1;
             three = -1;
         }
-        if (active) out[r] = sk_cut_dev{five, three};
+        // (staged kernels: no refill above, the next tile's pieces went out before the scan.  Tried and dropped: the cuts
+        // stored a turn late, so that the next turn's wait for its pieces does not sit out this store -- 1-7 % slower)
+        if (STAGE && scatter) index_settle(oidx);
+        if (active) out[scatter ? (uint64_t)oidx : r] = sk_cut_dev{five, three};
         // this trip's LDS reads are complete (their results were consumed) before the next
         // trip may overwrite the buffer they came from
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -809,13 +943,25 @@ sk_scan_tile_sorted_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
 // wave hold the scan state and the next tile, three waves per SIMD (12 per CU) at STAGE = 10
 template <int STAGE, int ABLATE = 0>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAGE > 10 ? 2 : 3, STAGE > 10 ? 3 : 4)))
 sk_scan_tile_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                            const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
                            unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles = nullptr,
                            const uint32_t *__restrict__ out_index = nullptr)
 {
     sk_scan_tile_body<true, false, true, 1, ABLATE, false, STAGE, false>(qual, seq, lengths, out, errword, a, tiles, out_index, nullptr);
+}
+
+// segmented batches without -n whose rows fit 20 KiB tiles (strides up to 320): the register-staged variant, tile
+// by tile as many pieces as the tile has (STAGE = the most: 10 or 20)
+template <int STAGE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STAGE > 10 ? 2 : 3, STAGE > 10 ? 2 : 3)))
+sk_scan_seg_staged_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
+                          const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
+                          unsigned long long *errword, sk_scan_args a, const sk_tile_dev *__restrict__ tiles,
+                          const uint32_t *__restrict__ out_index)
+{
+    sk_scan_tile_body<true, false, true, 1, 0, 2, STAGE, false>(qual, seq, lengths, out, errword, a, tiles, out_index, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -914,6 +1060,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_tile(const
 #define SK_STAGED(P) case P: return launch_tile_kernel(sk_scan_tile_staged_kernel<P>, 1, qual, seq, lengths, out, errword, a, cu_count, 0, stream, true)
             switch (pieces) {
                 SK_STAGED(5); SK_STAGED(6); SK_STAGED(7); SK_STAGED(8); SK_STAGED(9); SK_STAGED(10);
+                SK_STAGED(11); SK_STAGED(12); SK_STAGED(13); SK_STAGED(14); SK_STAGED(15); SK_STAGED(16);
+                SK_STAGED(17); SK_STAGED(18); SK_STAGED(19); SK_STAGED(20);
             default: break;
             }
 #undef SK_STAGED
@@ -956,15 +1104,24 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
         sk_scan_args as = *a;
         as.buf_bytes = lds_bytes;
         as.n_tiles = k.n_tiles;
-        auto launch = [&](auto kern) {
+        auto launch = [&](auto kern, int wg_per_cu = 0) {
             const kernel_facts facts = prepare_kernel(kern);
             if (facts.status != hipSuccess) return facts.status;
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq,
+            uint64_t g = grid;
+            if (wg_per_cu > 0 && wg_per_cu < per_cu) { // bounded by registers, not by LDS
+                g = (uint64_t)cu_count * wg_per_cu;
+                if (g > chunks) g = chunks;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), lds_bytes, stream, qual, seq,
                                (const uint32_t *)nullptr, out, errword, as, tiles + k.first_tile, out_index);
             return hipGetLastError();
         };
         hipError_t e;
-        if (a->truncn) e = k.wide ? launch(sk_scan_tile_kernel<true, true, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, true, true, 1, 0, 2>);
+        // no -n, windows <= 33, rows up to 320 bytes: the next tile waits in the wave's registers (SK_SEG_STAGE=0: A/B runs)
+        static const bool seg_stage = [] { const char *v = getenv("SK_SEG_STAGE"); return !(v && *v == '0'); }();
+        if (seg_stage && !a->truncn && !k.wide && k.max_stride <= 320u)
+            e = k.max_stride <= 160u ? launch(sk_scan_seg_staged_kernel<10>, 12) : launch(sk_scan_seg_staged_kernel<20>, 8);
+        else if (a->truncn) e = k.wide ? launch(sk_scan_tile_kernel<true, true, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, true, true, 1, 0, 2>);
         else e = k.wide ? launch(sk_scan_tile_kernel<true, false, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, false, true, 1, 0, 2>);
         if (e != hipSuccess) return e;
     }

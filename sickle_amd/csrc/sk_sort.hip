@@ -19,7 +19,7 @@
 // the locality is lost).
 //
 // Whether the sorted scan runs at all is decided on the device, and the scans read the verdict there (all of them are
-// enqueued, the ones it goes against return at once): counts[8] = windows whose reads differ in length, from a
+// enqueued, the ones it goes against return at once): counts[8] != 0: some window's reads differ in length, from a
 // look at the first eighth of every window (sk_sort_sample_kernel: a batch of one length must not pay for a regrouping it does not
 // need -- 8 bytes per read written and read again; a mix that only shows in the other windows keeps the plain tile
 // kernel, which is slower, not wrong); counts[9] = reads longer than the tile buffers take, counted exactly by the
@@ -35,7 +35,9 @@ sk_sort_sample_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     const uint64_t first = offsets[r0 + 1] - offsets[r0];
     bool differs = false;
     for (uint32_t k = threadIdx.x; k < m; k += 256u) differs |= offsets[r0 + k + 1] - offsets[r0 + k] != first;
-    if (__builtin_amdgcn_ballot_w64(differs) && (threadIdx.x & 63) == 0) atomicAdd(&counts[8], 1u);
+    // (a flag, not a count: one plain store per workgroup -- an atomic per wave, ~2 000 on one address, took 20 of this
+    // kernel's 25 us)
+    if (__syncthreads_or(differs) && threadIdx.x == 0) counts[8] = 1u;
 }
 
 template <int THREADS>

@@ -47,7 +47,9 @@ def test_kernel_selection():
     b = capi.Batch(q.ctypes.data, q.ctypes.data, None, 152, 150, None, 10)
     assert capi.lib().sk_kernel_for(b) == 1  # with a sequence buffer (-n): LDS-DMA tiles
     b = capi.Batch(q.ctypes.data, None, None, 264, 250, None, 10)
-    assert capi.lib().sk_kernel_for(b) == 1  # longer rows
+    assert capi.lib().sk_kernel_for(b) == 4  # rows up to 320 bytes too (20 pieces)
+    b = capi.Batch(q.ctypes.data, None, None, 328, 325, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 1  # longer rows: LDS-DMA tiles
     assert capi.lib().sk_kernel_name(4) == b"sk_scan_tile_staged_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 150, 150, None, 10)
     assert capi.lib().sk_kernel_for(b) == 5  # packed rows (stride not a multiple of 8): tiles with rows at any address
