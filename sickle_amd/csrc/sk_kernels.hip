@@ -289,34 +289,44 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         return v;
     };
 
-    // SORT: a tile's descriptor (32 bytes through the scalar cache) and its 64 entries (8 bytes per lane) lie where the
-    // tile's number says, so both loads go out together -- at the top of the turn BEFORE, ahead of the wait for that
-    // turn's tile (vmcnt(1) leaves the entry load in flight) -- and the entries are looked at when that turn's scan is
-    // over: the first version took descriptor, window bounds and entries one after the other at the start of every
-    // scan, 2-3 us of exposed latency per tile.
+    // SORT: a tile's descriptor (32 bytes, every lane the same address) and its 64 entries (8 bytes per lane) lie where
+    // the tile's number says.  Both are VECTOR loads, issued once the turn's tile has landed and looked at when the
+    // turn's scan is over -- the scan covers them.  (The first version took descriptor, window bounds and entries one
+    // after the other at the start of every scan, 2-3 us of exposed latency per tile; the second loaded the descriptor
+    // through the scalar cache at the top of the turn and waited for it there: a scalar load shares its counter with
+    // the LDS reads, there is no place in a scan where it could stay in flight.)
     struct sort_raw {
-        sk_v4u d0, d1; // the descriptor's eight dwords (scalar registers)
+        sk_v4u d0, d1; // the descriptor's eight dwords (d1[3] unused)
         uint64_t e;    // this lane's entry
     };
     auto sort_issue = [&](uint64_t tt) -> sort_raw {
         sort_raw q;
-        const unsigned long long *dp = in_sgprs(slist + 4u * tt);
-        // (waited for here: at the top of a turn the wait for the turn's tile follows and covers it; a scalar register
-        // with its load still pending is nothing the compiler could be kept from copying)
-        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(q.d0), "=&s"(q.d1) : "s"(dp) : "memory");
+        uint32_t at = (uint32_t)tt * 32u; // (< 2^27 tiles per list)
+        asm volatile("" : "+v"(at));     // a vector offset: global_load, counted by vmcnt
+        const uint8_t *dp = reinterpret_cast<const uint8_t *>(slist) + at;
+        q.d0 = *reinterpret_cast<const sk_v4u *>(dp);
+        q.d1 = *reinterpret_cast<const sk_v4u *>(dp + 16);
         q.e = perm[tt * 64u + (uint32_t)lane];
         return q;
     };
-    auto sort_finish = [&](sort_raw q) -> sk_tile_view {
+    auto first = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    int sort_lmax = 0, sort_lmin = 0, sort_w = 0; // of the tile being scanned (wave-uniform, from its descriptor)
+    int next_lmax = 0, next_lmin = 0, next_w = 0;
+    auto sort_finish = [&](const sort_raw &q) -> sk_tile_view {
         sk_tile_view v;
-        const uint64_t widx = q.d0[0];
-        v.rows = (q.d0[1] >> 16) & 0xffu;
-        v.off = ((uint64_t)q.d0[3] << 32) | q.d0[2];
-        v.bytes = q.d1[1] ? 0xffffffffu : q.d1[0];
+        const uint32_t d00 = first(q.d0[0]), d01 = first(q.d0[1]), d02 = first(q.d0[2]), d03 = first(q.d0[3]);
+        const uint32_t d10 = first(q.d1[0]), d11 = first(q.d1[1]), d12 = first(q.d1[2]);
+        const uint64_t widx = d00;
+        v.rows = (d01 >> 16) & 0xffu;
+        next_w = (int)(d01 >> 24);
+        next_lmax = (int)(d12 & 0xffffu);
+        next_lmin = (int)(d12 >> 16);
+        v.off = ((uint64_t)d03 << 32) | d02;
+        v.bytes = d11 ? 0xffffffffu : d10;
         v.rowoff = (uint32_t)lane < v.rows ? (uint32_t)q.e : 0u;
         v.len = (uint32_t)lane < v.rows ? (int)((uint32_t)(q.e >> 32) & 0xffffu) : 0;
         v.r = widx * SK_SORT_WINDOW + (uint32_t)(q.e >> 48);
-        v.ts = rag_pitch<false>((uint32_t)wave_max(v.len));
+        v.ts = rag_pitch<false>((uint32_t)next_lmax);
         v.take = true; // (the sort sends a batch with a read too long for the tiles to the other kernels)
         v.uni = true;  // here: ONE window width
         return v;
@@ -438,9 +448,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 
     // prologue: Q(t) [and S(t)] in flight
     sk_tile_view cur = SORT ? sort_finish(sort_issue(t)) : probe(t), nxt = cur;
-    if (TABLE) band_next = band_fetch(width_of(__builtin_amdgcn_readfirstlane(cur.len))); // (wu == 0: the first turn installs it)
-    sort_raw raw;
-    raw.e = 0;
+    if (TABLE) band_next = band_fetch(SORT ? next_w : width_of(cur.len)); // (wu == 0: the first turn installs it)
+    sort_raw raw{{0, 0, 0, 0}, {0, 0, 0, 0}, 0};
     if (SEG) probe_index(cur);
     bool cur_staged = STAGE && cur.rows == 64u;
     if (cur_staged) {
@@ -479,13 +488,14 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const int Lv = UNIFORM ? 0 : cur.len; // mixed lengths: this lane's length (0 past the end of the batch)
         bool tile_u = false; // MIXED: this tile's reads have one length (and a window the matrix path takes)
         if (MIXED && SORT) {
-            // one window width w for the tile's reads (lane 0 has one of them): any length with that width builds the band
-            const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
-            const int w0 = l0 / 10 ? l0 / 10 : l0;
-            tile_u = w0 > 0;
-            if (tile_u && w0 != wu) {
+            // one window width w for the tile's reads, in its descriptor: any length with that width names the band
+            sort_lmax = next_lmax;
+            sort_lmin = next_lmin;
+            sort_w = next_w;
+            tile_u = sort_w > 0;
+            if (tile_u && sort_w != wu) {
                 install_band(band_next);
-                set_scalars(l0);
+                set_scalars(sort_lmax);
             }
         } else if (MIXED) {
             const int l0 = __builtin_amdgcn_readfirstlane(cur.len);
@@ -493,19 +503,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             if (tile_u && l0 != Lu) set_length(l0);
         }
 
-        int band_loads = 0; // SORT: vector loads issued at the top of this turn behind the entry load
-        if (SORT && more) {
-            raw = sort_issue(tn);
-            const int wn = (int)(raw.d0[1] >> 24); // the next tile's window width (its class; 0: empty reads, no band)
-            if (wn != wu && wn != 0) {
-                band_next = band_fetch(wn);
-                band_loads = 3;
-            }
-        }
         if (SORT) {
             tile = buf0;
-            if (more) wait_vmcnt(1 + band_loads); // Q(t); the entry load of the next tile (and its band) stay in flight
-            else wait_vmcnt(0);
+            wait_vmcnt(0); // Q(t)
+            if (more) raw = sort_issue(tn); // looked at when this turn's scan is over
         } else if (SEQ_SHARES || RAG) {
             tile = buf0;
             wait_vmcnt(0); // Q(t)
@@ -608,11 +609,12 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const int nwin = (UNIFORM ? scan_u : scanned) ? L - w + 1 : 0;
         const int m = w >> 2, sh = w & 3;
         // one value per wave: known (uniform batch), the lanes' common value (uniform tile of a ragged batch), or reduced
-        const int Lmax = UNIFORM ? L : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(L) : wave_max(L);
-        const int wmax = UNIFORM ? w : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(w) : wave_max(w);
-        const int nwinmax = UNIFORM ? nwin : (tile_u && !SORT) ? __builtin_amdgcn_readfirstlane(nwin) : wave_max(nwin);
-        // the dwords every scanned read of the tile has in full (SORT: lengths differ by < 10 inside a tile)
-        const int Lfull = SORT ? -wave_max(scanned ? -L : -0x7fffff) : Lmax;
+        // (SORT: the longest and the shortest read of the tile and their one window width come with the descriptor)
+        const int Lmax = UNIFORM ? L : SORT ? sort_lmax : tile_u ? __builtin_amdgcn_readfirstlane(L) : wave_max(L);
+        const int wmax = UNIFORM ? w : SORT ? sort_w : tile_u ? __builtin_amdgcn_readfirstlane(w) : wave_max(w);
+        const int nwinmax = UNIFORM ? nwin : SORT ? (sort_w > 0 ? sort_lmax - sort_w + 1 : 0) : tile_u ? __builtin_amdgcn_readfirstlane(nwin) : wave_max(nwin);
+        // the dwords every read of the tile has in full (SORT: lengths differ by < 10 inside a tile)
+        const int Lfull = SORT ? sort_lmin : Lmax;
 
         // ---- range check of the whole read in 2 ops per dword: for a char c in [min,max],
         // |c-min| + |c-max| == max-min, and it is larger for every other byte value, so the
@@ -870,7 +872,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             if (nlo != NONE) three = (int)(nlo >> 3) - 1;
             else if (anyN) three = -2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (SORT && more) nxt = sort_finish(raw);
+            if (SORT && more) {
+                nxt = sort_finish(raw);
+                if (next_w != wu && next_w != 0) band_next = band_fetch(next_w);
+            }
             if (more) {
                 if (SEQ_SHARES) { if (nxt.take) load_tile(qual, buf0, nxt); }   // Q(t+1)
                 else tile_to_lds(seq + nxt.off, buf1, next_bytes, lane);      // S(t+1)
@@ -881,7 +886,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // ragged last tile of the batch takes this way.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (scatter) index_settle(oidx);
-            if (SORT && more) nxt = sort_finish(raw);
+            if (SORT && more) {
+                nxt = sort_finish(raw);
+                if (next_w != wu && next_w != 0) band_next = band_fetch(next_w);
+            }
             if (more && nxt.take) load_tile(qual, buf0, nxt);
         }
 #if SK_TAIL_PRIO

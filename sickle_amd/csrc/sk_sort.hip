@@ -7,7 +7,8 @@
 // matrix path needs is one window width w per tile (the band matrix), not one length: reads of 10 w .. 10 w + 9 bases
 // share it.  So the batch is cut into windows of SK_SORT_WINDOW consecutive reads, and one workgroup per window
 // counting-sorts the window's reads by w (52 classes: histogram, prefix, scatter -- in LDS; no quality byte moves):
-//   tile lists: per class ceil(count / 64) tiles, 32 bytes each: {window, rows, w; where the window starts in the batch; its bytes}
+//   tile lists: per class ceil(count / 64) tiles, 32 bytes each: {window, rows, w; where the window starts in the batch; its bytes;
+//               the longest and the shortest read of the tile}
 //   perm: 64 entries per tile, in list order: {offset of the read inside its window, its length, its number in the window}
 // (a tile's entries lie where the scan can compute: it loads descriptor and entries side by side, a tile ahead)
 // The scan (sk_scan_tile_body, SORT) then gathers a tile's rows by the re-striding loader -- a row start per lane.
@@ -45,13 +46,14 @@ __global__ void __launch_bounds__(THREADS)
 sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t max_len, uint64_t *__restrict__ perm,
                        unsigned long long *__restrict__ lists, uint32_t list_cap, uint32_t *__restrict__ counts /* [8] tiles per list, [8] flags[0], [9] flags[1] */)
 {
-    constexpr int W = SK_SORT_WINDOW, PER = W / THREADS, NC = 64;
-    __shared__ uint32_t hist[NC], cursor[NC], tbase[NC], gbase;
+    constexpr int W = SK_SORT_WINDOW, PER = W / THREADS, NC = 64, NT = W / 64 + NC; // NT: more tiles than a window can have
+    __shared__ uint32_t hist[NC], cursor[NC], tbase[NC], gbase, tmax[NT], tmin[NT];
     if (counts[8] == 0) return; // a batch of one length (as far as the sample saw): nothing to regroup
     const int t = threadIdx.x;
     const uint64_t widx = blockIdx.x, r0 = widx * W;
     const uint32_t m = (uint32_t)min((uint64_t)W, n_reads - r0);
     if (t < NC) hist[t] = 0, cursor[t] = 0;
+    if (t < NT) tmax[t] = 0, tmin[t] = 0xffffu;
     __syncthreads();
     const uint64_t wstart = offsets[r0];
     uint32_t ro[PER];
@@ -100,11 +102,14 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
         const uint32_t k = (uint32_t)t + (uint32_t)i * THREADS;
         if (cl[i] != 255) {
             const uint32_t rank = atomicAdd(&cursor[cl[i]], 1u); // the read's place in its class: tile rank / 64, lane rank % 64
-            const uint32_t tile = gbase + tbase[cl[i]] + (rank >> 6);
+            const uint32_t ltile = tbase[cl[i]] + (rank >> 6), tile = gbase + ltile;
+            atomicMax(&tmax[ltile], (uint32_t)ln[i]); // the longest and the shortest read of the tile: the scan sizes its image
+            atomicMin(&tmin[ltile], (uint32_t)ln[i]); // and its unmasked loops by them, without a reduction over the lanes
             if (tile < list_cap)
                 perm[((size_t)(widx & 7u) * list_cap + tile) * 64u + (rank & 63u)] = (uint64_t)ro[i] | ((uint64_t)ln[i] << 32) | ((uint64_t)k << 48);
         }
     }
+    __syncthreads();
     if (t < NC) {
         const uint32_t cnt = hist[t], nt = (cnt + 63u) >> 6;
         unsigned long long *dst = lists + ((size_t)(widx & 7u) * list_cap + gbase + tbase[t]) * 4u;
@@ -115,7 +120,7 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
                 dst[4 * j] = (unsigned long long)widx | ((unsigned long long)rows << 48) | ((unsigned long long)t << 56);
                 dst[4 * j + 1] = wstart;
                 dst[4 * j + 2] = span;
-                dst[4 * j + 3] = 0;
+                dst[4 * j + 3] = (unsigned long long)tmax[tbase[t] + j] | ((unsigned long long)tmin[tbase[t] + j] << 16);
             }
         }
     }
