@@ -36,7 +36,9 @@ constexpr uint32_t SK_SEG_MAX_CLASSES = 16;
 struct SortScratch {
     uint64_t *perm = nullptr;            // 8 lists x cap_list tiles x 64 entries
     unsigned long long *lists = nullptr; // 8 lists x cap_list descriptors of 32 bytes
-    uint32_t *counts = nullptr;          // tiles per list [8], flags [2]
+    uint32_t *counts = nullptr;          // 2 x 16 words: tiles per list [8], flags [2] -- one set per scan, in turns: a scan's
+                                         // first kernel clears the set of the scan after it (no memset on the launch path)
+    uint32_t turn = 0;
     size_t cap_list = 0;
     void release_lists()
     {
@@ -262,7 +264,11 @@ bool ensure_sort(sk_ctx *ctx, SortScratch &s, uint64_t n)
     const size_t windows = (size_t)((n + SK_SORT_WINDOW - 1) / SK_SORT_WINDOW);
     const size_t per_list = ((windows + 7) / 8) * (SK_SORT_WINDOW / 64 + 64) + 8;
     if (hipSetDevice(ctx->device) != hipSuccess) return false;
-    if (!s.counts && hipMalloc(&s.counts, 16 * sizeof(uint32_t)) != hipSuccess) return false;
+    if (!s.counts) {
+        if (hipMalloc(&s.counts, 32 * sizeof(uint32_t)) != hipSuccess) return false;
+        if (hipMemset(s.counts, 0, 32 * sizeof(uint32_t)) != hipSuccess) return false; // synchronous: done before any scan is enqueued
+        s.turn = 0;
+    }
     if (per_list > s.cap_list) {
         s.release_lists();
         const size_t cap = per_list + (per_list >> 3);
@@ -306,18 +312,22 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         // batch of one length (or with long reads) is theirs as before and the sorted scan returns.  SK_SORT=0: never.
         static const bool sort_on = [] { const char *e = getenv("SK_SORT"); return !(e && *e == '0'); }();
         static const uint64_t sort_min = [] { const char *e = getenv("SK_SORT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)SK_SORT_MIN_READS; }(); // (tests lower it)
+        uint32_t *sort_counts = nullptr;
         const bool sorted = sort_on && sort && b->offsets && a->n_reads >= sort_min && ensure_sort(ctx, *sort, a->n_reads);
         if (sorted) {
             uint32_t fit = rag_fit_len(ar.buf_bytes);
             if (b->stride && b->stride < fit) fit = b->stride;
-            SK_HIP(ctx, sk_launch_sort(b->offsets, a->n_reads, fit, sort->perm, sort->lists, (uint32_t)sort->cap_list, sort->counts, stream));
-            ar.sort_flags = sort->counts + 8;
+            sort_counts = sort->counts + 16u * (sort->turn & 1u);
+            SK_HIP(ctx, sk_launch_sort(b->offsets, a->n_reads, fit, sort->perm, sort->lists, (uint32_t)sort->cap_list, sort_counts,
+                                       sort->counts + 16u * (~sort->turn & 1u), stream));
+            ++sort->turn;
+            ar.sort_flags = sort_counts + 8;
         }
         SK_HIP(ctx, sk_launch_any(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, ctx->cu_count, stream));
         if (sorted) {
             sk_scan_args as = ar;
             as.n_tiles = (uint32_t)sort->cap_list;
-            SK_HIP(ctx, sk_launch_sorted(b->qual, seq, b->offsets, sort->perm, sort->lists, sort->counts, out, d_err, &as, ctx->cu_count, stream));
+            SK_HIP(ctx, sk_launch_sorted(b->qual, seq, b->offsets, sort->perm, sort->lists, sort_counts, out, d_err, &as, ctx->cu_count, stream));
         }
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)

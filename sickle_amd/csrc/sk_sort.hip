@@ -29,8 +29,9 @@
 
 // the first eighth of every window: do its reads differ in length?
 __global__ void __launch_bounds__(256)
-sk_sort_sample_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t *__restrict__ counts)
+sk_sort_sample_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t *__restrict__ counts, uint32_t *__restrict__ counts_of_next_scan)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 16) counts_of_next_scan[threadIdx.x] = 0; // (this scan's were cleared by the scan before)
     const uint64_t r0 = (uint64_t)blockIdx.x * SK_SORT_WINDOW;
     const uint32_t m = (uint32_t)min((uint64_t)(SK_SORT_WINDOW / 8), n_reads - r0);
     const uint64_t first = offsets[r0 + 1] - offsets[r0];
@@ -41,51 +42,80 @@ sk_sort_sample_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     if (__syncthreads_or(differs) && threadIdx.x == 0) counts[8] = 1u;
 }
 
+// One workgroup per window.  Thread t takes the window's reads 8t .. 8t+7 (a wave: 512 consecutive reads), and the
+// counting is done PER WAVE: 16 x 64 counters in LDS, so that the LDS atomics of a wave only meet the atomics of its own
+// 64 lanes (one counter set per workgroup put all 8192 reads of a window on ~23 addresses, twice, one after the other:
+// the kernel spent 15 of its 21 us there).  A class's reads are then ranked wave by wave -- a tile's 64 reads come from
+// two or three neighbouring waves' stretches of the window, ~200 KB instead of the window's 1.5 MB.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
 sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t max_len, uint64_t *__restrict__ perm,
                        unsigned long long *__restrict__ lists, uint32_t list_cap, uint32_t *__restrict__ counts /* [8] tiles per list, [8] flags[0], [9] flags[1] */)
 {
-    constexpr int W = SK_SORT_WINDOW, PER = W / THREADS, NC = 64, NT = W / 64 + NC; // NT: more tiles than a window can have
-    __shared__ uint32_t hist[NC], cursor[NC], tbase[NC], gbase, tmax[NT], tmin[NT];
+    constexpr int W = SK_SORT_WINDOW, PER = W / THREADS, NC = 64, NW = THREADS / 64, NT = W / 64 + NC; // NT: more tiles than a window can have
+    __shared__ uint32_t cnt_w[NW][NC]; // per wave and class: count, then the rank its first read of the class gets
+    __shared__ uint32_t hist[NC], tbase[NC], gbase, tmax[NT], tmin[NT];
+    __shared__ uint32_t rel[W + 1]; // the window's offsets relative to its first (loaded lane by lane, read 9 per thread)
     if (counts[8] == 0) return; // a batch of one length (as far as the sample saw): nothing to regroup
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, wave = t >> 6;
     const uint64_t widx = blockIdx.x, r0 = widx * W;
     const uint32_t m = (uint32_t)min((uint64_t)W, n_reads - r0);
-    if (t < NC) hist[t] = 0, cursor[t] = 0;
+    for (int i = t; i < NW * NC; i += THREADS) (&cnt_w[0][0])[i] = 0;
     if (t < NT) tmax[t] = 0, tmin[t] = 0xffffu;
     __syncthreads();
     const uint64_t wstart = offsets[r0];
+    uint32_t nlong = 0;
+#pragma unroll
+    for (int i = 0; i <= PER; ++i) {
+        const uint32_t k = (uint32_t)t + (uint32_t)i * THREADS;
+        if (k <= m && (i < PER || t == 0)) {
+            const uint64_t o = offsets[r0 + k];
+            if (o < wstart || o - wstart > 0xffffffffull) ++nlong; // a window beyond 4 GiB, or offsets that do not ascend: not for the tiles
+            rel[k] = (uint32_t)(o - wstart);
+        }
+    }
+    __syncthreads();
     uint32_t ro[PER];
     uint16_t ln[PER];
     uint8_t cl[PER];
-    uint32_t nlong = 0;
+    const uint32_t k0 = (uint32_t)t * PER;
+    uint32_t o = k0 < m ? rel[k0] : 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const uint32_t k = (uint32_t)t + (uint32_t)i * THREADS;
+        const uint32_t k = k0 + (uint32_t)i;
         cl[i] = 255;
         if (k < m) {
-            const uint64_t o = offsets[r0 + k], e = offsets[r0 + k + 1];
-            const uint64_t L64 = e >= o ? e - o : 0;
-            const uint32_t L = (uint32_t)min(L64, (uint64_t)0xffffu);
+            const uint32_t e = rel[k + 1];
+            const uint32_t L64 = e - o; // (not ascending: wraps to a length no tile takes)
+            const uint32_t L = min(L64, 0xffffu);
             uint32_t c;
-            if (L64 > max_len || o < wstart || o - wstart > 0xffffffffull) { // not for the tiles (or offsets that do not ascend)
+            if (L64 > max_len) {
                 c = 63;
                 ++nlong;
             } else {
                 const uint32_t w = L / 10 ? L / 10 : L; // reference src/trim.cpp:8, :30
                 c = w; // 0 (an empty read) .. 50
             }
-            ro[i] = (uint32_t)(o - wstart);
+            ro[i] = o;
             ln[i] = (uint16_t)L;
             cl[i] = (uint8_t)c;
-            atomicAdd(&hist[c], 1u);
+            atomicAdd(&cnt_w[wave][c], 1u);
+            o = e;
         }
     }
     __syncthreads();
-    // exclusive prefixes over the 64 classes: slots, tiles (one wave)
+    // per class: the waves' counts -> where each wave's reads of the class begin; then exclusive prefixes over the 64
+    // classes: tiles (one wave)
     if (t < NC) {
-        const uint32_t cnt = hist[t], nt = (cnt + 63u) >> 6;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t c = cnt_w[w][t];
+            cnt_w[w][t] = run;
+            run += c;
+        }
+        hist[t] = run;
+        const uint32_t nt = (run + 63u) >> 6;
         uint32_t q = nt;
 #pragma unroll
         for (int d = 1; d < NC; d <<= 1) {
@@ -99,9 +129,9 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const uint32_t k = (uint32_t)t + (uint32_t)i * THREADS;
+        const uint32_t k = k0 + (uint32_t)i;
         if (cl[i] != 255) {
-            const uint32_t rank = atomicAdd(&cursor[cl[i]], 1u); // the read's place in its class: tile rank / 64, lane rank % 64
+            const uint32_t rank = atomicAdd(&cnt_w[wave][cl[i]], 1u); // the read's place in its class: tile rank / 64, lane rank % 64
             const uint32_t ltile = tbase[cl[i]] + (rank >> 6), tile = gbase + ltile;
             atomicMax(&tmax[ltile], (uint32_t)ln[i]); // the longest and the shortest read of the tile: the scan sizes its image
             atomicMin(&tmin[ltile], (uint32_t)ln[i]); // and its unmasked loops by them, without a reduction over the lanes
@@ -113,7 +143,7 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
     if (t < NC) {
         const uint32_t cnt = hist[t], nt = (cnt + 63u) >> 6;
         unsigned long long *dst = lists + ((size_t)(widx & 7u) * list_cap + gbase + tbase[t]) * 4u;
-        const unsigned long long span = offsets[r0 + m] - wstart;
+        const unsigned long long span = rel[m]; // (a window beyond 4 GiB is flagged above: the batch then goes to the other kernels)
         for (uint32_t j = 0; j < nt; ++j) {
             const uint32_t rows = min(64u, cnt - 64u * j);
             if (gbase + tbase[t] + j < list_cap) {
@@ -127,14 +157,12 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
 }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sort(const uint64_t *offsets, uint64_t n_reads, uint32_t max_len, uint64_t *perm,
-                                     unsigned long long *lists, uint32_t list_cap, uint32_t *counts, hipStream_t stream)
+                                     unsigned long long *lists, uint32_t list_cap, uint32_t *counts, uint32_t *counts_of_next_scan,
+                                     hipStream_t stream)
 {
-    if (n_reads == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(counts, 0, 16 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
     const uint64_t windows = (n_reads + SK_SORT_WINDOW - 1) / SK_SORT_WINDOW;
-    hipLaunchKernelGGL(sk_sort_sample_kernel, dim3((unsigned)windows), dim3(256), 0, stream, offsets, n_reads, counts);
-    e = hipGetLastError();
+    hipLaunchKernelGGL(sk_sort_sample_kernel, dim3((unsigned)windows), dim3(256), 0, stream, offsets, n_reads, counts, counts_of_next_scan);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sk_sort_windows_kernel<1024>, dim3((unsigned)windows), dim3(1024), 0, stream, offsets, n_reads, max_len, perm, lists,
                        list_cap, counts);
