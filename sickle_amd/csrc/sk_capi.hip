@@ -225,6 +225,16 @@ hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_
                       : sk_launch_band(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
 }
 
+// uniform medium reads (rows beyond the 64-read tiles, windows of 32 and more, two waves' images to a CU): the tile kernel
+// with 32-read tiles (sk_kernels.hip, WIDE).  SK_GENERAL=team|band|stream sends them to a general kernel instead (A/B runs,
+// tests), SK_WIDE_MAX bounds the lengths it takes.
+bool wide_takes(const sk_batch *b)
+{
+    if (b->offsets || b->lengths || b->tiles || getenv("SK_GENERAL")) return false;
+    static const uint32_t wide_max = [] { const char *e = getenv("SK_WIDE_MAX"); return e ? (uint32_t)atoi(e) : 2528u; }();
+    return b->read_len <= wide_max && sk_wide_lds_bytes(b->read_len) != 0;
+}
+
 int path_of(const sk_batch *b)
 {
     if (b->tiles) return 3;
@@ -332,6 +342,8 @@ int enqueue_scan(sk_ctx *ctx, const sk_scan_args *a, const sk_batch *b, sk_cut_d
         // the tiles that kernel leaves: those whose reads are too long for a wave's buffer (none in a
         // packed uniform batch)
         if (ragged) SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, &ar, b->stride, ctx->cu_count, stream));
+    } else if (wide_takes(b)) {
+        SK_HIP(ctx, sk_launch_wide(b->qual, seq, out, d_err, a, ctx->cu_count, stream));
     } else {
         SK_HIP(ctx, launch_general(b->qual, seq, b->offsets, b->lengths, out, d_err, a, b->read_len, ctx->cu_count, stream));
     }
@@ -572,6 +584,7 @@ int sk_kernel_for(const sk_batch *batch)
         const bool ragged = batch->offsets || batch->lengths;
         const uint64_t longest = ragged ? batch->stride : batch->read_len;
         const bool general_only = path == 2 || (path == 5 && batch->offsets && batch->stride > SK_LONG_BATCH_HINT);
+        if (path == 2 && wide_takes(batch)) return 8;
         return general_only ? ((longest == 0 || longest > SK_STREAM_MIN_DEFAULT) ? 6 : 2) : path;
     }
     // uniform batches without a sequence buffer (no -n) and rows of 72..160 bytes: the tile comes in
@@ -636,6 +649,7 @@ const char *sk_kernel_name(int which)
     case 5: return "sk_scan_tile_any_kernel";
     case 6: return "sk_scan_stream_kernel";
     case 7: return "sk_scan_band_kernel";
+    case 8: return "sk_scan_tile_wide_kernel";
     default: return "";
     }
 }

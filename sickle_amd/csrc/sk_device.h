@@ -105,6 +105,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_stream(con
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets,
                                     const uint32_t *lengths, sk_cut_dev *out, unsigned long long *errword,
                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) uint32_t sk_wide_lds_bytes(uint32_t read_len);
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const uint8_t *qual, const uint8_t *seq, sk_cut_dev *out, unsigned long long *errword,
+                                     const sk_scan_args *a, int cu_count, hipStream_t stream);
 // mixed-length ragged batches: the per-window regrouping (sk_sort.hip) and the scan of its tiles (sk_kernels.hip)
 extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sort(const uint64_t *offsets, uint64_t n_reads, uint32_t max_len, uint64_t *perm,
                                      unsigned long long *lists, uint32_t list_cap, uint32_t *counts, uint32_t *counts_of_next_scan,

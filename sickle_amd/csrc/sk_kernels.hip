@@ -96,7 +96,17 @@
 // window width, not in length, anywhere inside their window of SK_SORT_WINDOW consecutive reads.  One band per tile,
 // so the matrix path; lengths, window counts and the masks of the range check stay per lane.  (tiles = the lists,
 // out_index = perm, lengths = the lists' tile counts.)
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false>
+// WIDE (uniform MEDIUM reads, 505 bytes to a few thousand: rows too long for 64 of them to share a wave's LDS buffer
+// with enough other waves on the CU): tiles of 32 reads, a PAIR of lanes per read -- lane n and lane n + 32 hold the two
+// halves of read n's 16-byte operand fragments, which is how one v_mfma_i32_32x32x32_i8 wants 32 reads anyway, and each
+// gets 16 of the read's 32 window sums; a v_permlane32_swap hands both lanes all 32 sign bits and both run the read's
+// state (everything after the matrix path is per read and done by both lanes alike; lane n stores).  Windows of any
+// width from 32 up: the positions a window of 32 consecutive windows covers fall into a first block (triangular band),
+// dm = w / 32 - 1 blocks that EVERY one of the 32 windows covers whole, and two last blocks (the band's other edge).
+// The whole blocks need no band -- an all-ones matrix -- and their sum is carried from step to step in the accumulator
+// that also holds -T: entering block in (+ones), leaving block out (-ones).  Five MFMAs per 32 windows x 32 reads
+// whatever the width; two new fragments per step.
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false, bool WIDE = false>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                   const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
@@ -104,6 +114,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                   const uint32_t *__restrict__ out_index, const uint64_t *__restrict__ offsets)
 {
     static_assert(!SORT || (RAG && !UNIFORM && MFMA), "regrouped ragged batches: re-strided tiles, matrix path");
+    static_assert(!WIDE || (RAG && UNIFORM && MFMA && !SORT), "medium reads: uniform batches, re-strided tiles, matrix path");
+    constexpr uint32_t ROWS = WIDE ? 32u : 64u; // reads per tile
+    constexpr int RSHIFT = WIDE ? 5 : 6;
     static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
     static_assert(!MFMA || UNIFORM || RAG, "the matrix path needs one window width per tile");
     // MIXED (ragged batches): per-lane lengths in general, but a tile whose 64 reads have ONE length --
@@ -118,6 +131,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     constexpr bool SEQ_SHARES = HAS_SEQ && NBUF == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
+    const int rlane = WIDE ? (lane & 31) : lane; // the tile row (read) this lane works on
     // readfirstlane: tells the compiler this is one value per wave, so that the tile index and
     // everything derived from it (addresses, piece counts, loop and switch conditions) live in
     // SGPRs and branch on the scalar unit instead of being carried through the vector ALU
@@ -132,7 +146,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     const uint32_t xcd = SORT ? blockIdx.x & 7u : 0u;
     const unsigned long long *const slist = reinterpret_cast<const unsigned long long *>(tiles) + (size_t)xcd * a.n_tiles * 4u;
     const uint64_t *const perm = reinterpret_cast<const uint64_t *>(out_index) + (size_t)xcd * a.n_tiles * 64u;
-    const uint64_t n_tiles = SORT ? (uint64_t)min(scalar_load(lengths + xcd), a.n_tiles) : SEG ? (uint64_t)a.n_tiles : (a.n_reads + 63) >> 6;
+    const uint64_t n_tiles = SORT ? (uint64_t)min(scalar_load(lengths + xcd), a.n_tiles) : SEG ? (uint64_t)a.n_tiles : (a.n_reads + ROWS - 1) >> RSHIFT;
     uint64_t wave_global = SORT ? (uint64_t)(blockIdx.x >> 3) : (uint64_t)blockIdx.x * waves_per_block + wave;
     const uint64_t wave_count = SORT ? (uint64_t)((gridDim.x - xcd + 7u) >> 3) : (uint64_t)gridDim.x * waves_per_block;
     if (a.tile_order == 1 && (wave_count & 7) == 0) {
@@ -211,11 +225,13 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // of the loop and pins a register to each
             if (MIXED) asm volatile("" : "+v"(ln));
             const int k0 = (ln >> 5) * 16; // the first position (relative to 32*b) this lane's bytes multiply
+            // WIDE: the band's far edge lies in the blocks behind the dm whole ones
+            const int far = WIDE ? 32 * (wu / 32) : 32;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bandA0[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j);
-                bandA1[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + 32);
-                bandA2[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + 64);
+                bandA1[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + far);
+                bandA2[j] = (int)sk_band_dword(ln, wu, k0 + 4 * j + far + 32);
             }
         }
     };
@@ -259,12 +275,12 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             v.len = (int)d.read_len;
             v.r = d.slot0; // probe_index() turns it into this lane's slot of out[]
         } else if (RAG && UNIFORM) {
-            v.off = (tt << 6) * stride;
-            v.rows = (uint32_t)min((uint64_t)64, a.n_reads - (tt << 6));
+            v.off = (tt << RSHIFT) * stride;
+            v.rows = (uint32_t)min((uint64_t)ROWS, a.n_reads - (tt << RSHIFT));
             v.ts = rag_pitch<true>(a.read_len);
             v.bytes = (v.rows - 1u) * stride + a.read_len;
             v.len = (int)a.read_len;
-            v.r = (tt << 6) + lane;
+            v.r = (tt << RSHIFT) + rlane;
         } else if (SORT) {
             // (sort_issue / sort_finish below: the loads go out a tile ahead)
         } else if (RAG) {
@@ -403,7 +419,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     if (p + (uint32_t)u < cpr) piece(p + (uint32_t)u, ro[u], cq[u]);
             }
         } else {
-            for (uint32_t p = 0; p < cpr; ++p) {
+            const uint32_t pieces = WIDE ? (cpr + 1u) >> 1 : cpr; // (32 rows: the last piece's upper lanes fetch the tile's last bytes again)
+            for (uint32_t p = 0; p < pieces; ++p) {
                 uint32_t ro;
                 if (UNIFORM) ro = rr * stride;
                 else if (v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
@@ -484,7 +501,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const int next_pieces = (PROBE_EARLY && more) ? tile_pieces(next_bytes) : 0;
         const uint8_t *tile;
 
-        const bool active = (uint32_t)lane < cur.rows;
+        const bool active = (uint32_t)rlane < cur.rows;
         const int Lv = UNIFORM ? 0 : cur.len; // mixed lengths: this lane's length (0 past the end of the batch)
         bool tile_u = false; // MIXED: this tile's reads have one length (and a window the matrix path takes)
         if (MIXED && SORT) {
@@ -589,7 +606,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             cur = nxt;
             continue;
         }
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)lane * ts);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (size_t)rlane * ts);
         if (ABLATE == 1) {
             const sk_cut_dev dummy{(int)row[0], (int)row[1]};
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -622,21 +639,32 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         // decided below against the part of the read the reference would have touched.)
         uint32_t sad = 0;
         {
+            const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
+            auto sad8 = [&](int k, uint32_t &acc) { // dwords k .. k+7: 4 x ds_read_b64 in flight, then 16 SADs
+                uint64_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = row64[(k >> 1) + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = __builtin_amdgcn_sad_u8((uint32_t)x[u], min4, acc);
+                    acc = __builtin_amdgcn_sad_u8((uint32_t)x[u], max4, acc);
+                    acc = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), min4, acc);
+                    acc = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), max4, acc);
+                }
+            };
             int k = 0;
             if (UNIFORM || tile_u) {
                 const int full = (SORT ? min(Lfull, Lmax) : Lmax) >> 2; // whole dwords; rows are 8-byte aligned
-                const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
-                for (; k + 8 <= full; k += 8) { // 4 x ds_read_b64 in flight, then 16 SADs
-                    uint64_t x[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) x[u] = row64[(k >> 1) + u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        sad = __builtin_amdgcn_sad_u8((uint32_t)x[u], min4, sad);
-                        sad = __builtin_amdgcn_sad_u8((uint32_t)x[u], max4, sad);
-                        sad = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), min4, sad);
-                        sad = __builtin_amdgcn_sad_u8((uint32_t)(x[u] >> 32), max4, sad);
-                    }
+                if (WIDE) {
+                    // the two lanes of a read take its 8-dword groups in turns and add up what they found
+                    int groups = 0;
+                    for (int g = half; 8 * g + 8 <= full; g += 2, ++groups) sad8(8 * g, sad);
+                    sad -= (uint32_t)(32 * groups * range);
+                    const sk_v2u both = __builtin_amdgcn_permlane32_swap(sad, sad, false, false);
+                    sad = both[0] + both[1];
+                    k = full & ~7; // (the rest, below, by both alike)
+                } else {
+                    for (; k + 8 <= full; k += 8) sad8(k, sad);
                 }
                 for (; k + 2 <= full; k += 2) {
                     const uint64_t x = row64[k >> 1];
@@ -646,13 +674,14 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     sad = __builtin_amdgcn_sad_u8((uint32_t)(x >> 32), max4, sad);
                 }
             }
+            const int k_rest = WIDE ? (((SORT ? min(Lfull, Lmax) : Lmax) >> 2) & ~7) : 0; // dwords already accounted for
             for (; 4 * k < Lmax; ++k) { // per-lane masking: the last dword(s) (UNIFORM) / mixed lengths
                 const uint32_t x = first_bytes(row[k], L - 4 * k, min4);
                 sad = __builtin_amdgcn_sad_u8(x, min4, sad);
                 sad = __builtin_amdgcn_sad_u8(x, max4, sad);
             }
             // every dword visited contributes 4*range when clean (fillers are legal chars)
-            sad -= (uint32_t)(4 * k * range);
+            sad -= (uint32_t)(4 * (k - k_rest) * range);
         }
         const bool bad = scanned && sad != 0;
 
@@ -704,7 +733,56 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 const sk_v2u s = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
                 step32((s[0] << 16) | s[1], base);
             };
-            if (SEG == 2 || (SEG != 3 && !three_blocks)) { // w <= 33: positions base .. base+63, two trips per turn so that
+            if (WIDE) {
+                // one group of 32 reads; lane (n, half): 16 bytes of read n at positions 32 * block + 16 * half
+                const int dm = wu / 32 - 1;      // blocks every window of a step covers whole (wu >= 32)
+                const int far = 32 * (dm + 1);   // the first of the two blocks with the band's far edge
+                const sk_v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101}, minus = {-1, -1, -1, -1};
+                sk_v16i mid = negT; // -T + the whole blocks of the step
+                auto frag = [&](int blk) -> sk_v4i { return load_frag(frag0 + 32 * blk); };
+                for (int d = 1; d <= dm; ++d) mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, frag(d), mid, 0, 0, 0);
+                // the four fragments a step works on: blocks st, st + 1 and the two with the band's far edge
+                struct frags {
+                    sk_v4i q0, q1, qf, qg;
+                };
+                auto fetch = [&](int st) -> frags { return frags{frag(st), frag(st + 1), frag(st + dm + 1), frag(st + dm + 2)}; };
+                // the sums of a step, and `mid` moved on to the step after it: block st + dm + 1 in, block st + 1 out
+                auto sums = [&](const frags &f) -> sk_v16i {
+                    sk_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA0, f.q0, mid, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA1, f.qf, d0, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bandA2, f.qg, d0, 0, 0, 0);
+                    if (dm > 0) {
+                        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, f.qf, mid, 0, 0, 0);
+                        mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(minus, f.q1, mid, 0, 0, 0);
+                    }
+                    return d0;
+                };
+                auto signs = [&](const sk_v16i &d0, int base) {
+                    uint32_t p0 = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
+                    // lanes n and n + 32 both get windows 0..15 (from lane n) and 16..31 (from lane n + 32)
+                    const sk_v2u sw = __builtin_amdgcn_permlane32_swap(p0, p0, false, false);
+                    step32((sw[0] << 16) | sw[1], base);
+                };
+                // Two steps per turn; the fragments are read out of LDS two steps ahead and the matrix pipe runs one step
+                // ahead of the vector ALU: a step's five MFMAs are two dependent chains of 64 cycles a link, the sign
+                // collection of the step before runs underneath them.
+                frags fa = fetch(0), fb = fa;
+                if (32 < nwinmax) fb = fetch(1);
+                sk_v16i da = sums(fa), db = da;
+                for (int base = 0; base < nwinmax; base += 64) {
+                    const int st = base >> 5;
+                    const bool second = base + 32 < nwinmax, third = base + 64 < nwinmax;
+                    if (third) fa = fetch(st + 2);
+                    if (second) db = sums(fb);
+                    signs(da, base);
+                    if (!second) break;
+                    if (base + 96 < nwinmax) fb = fetch(st + 3);
+                    if (third) da = sums(fa);
+                    signs(db, base + 32);
+                }
+            } else if (SEG == 2 || (SEG != 3 && !three_blocks)) { // w <= 33: positions base .. base+63, two trips per turn so that
                                  // the fragment registers alternate instead of being copied
                 sk_v4i qa0 = load_frag(frag0), qa1 = load_frag(frag1);
                 for (int base = 0; base < nwinmax; base += 64) {
@@ -820,7 +898,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     if (f) { p = 4 * k + (__builtin_ctz(f) >> 3); break; }
                 }
                 // (segmented batches: r is the slot; the caller's read number is out_index[slot])
-                if (p < touched) report_error(errword, SEG ? (uint64_t)out_index[r] : r, p, (int)(int8_t)(tile[(size_t)lane * ts + p]));
+                if (p < touched) report_error(errword, SEG ? (uint64_t)out_index[r] : r, p, (int)(int8_t)(tile[(size_t)rlane * ts + p]));
             }
         }
 
@@ -837,7 +915,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 if (more) tile_to_lds(qual + nxt.off, buf0, next_bytes, lane);
                 wait_vmcnt(next_pieces); // older than Q(t+1): S(t)
             }
-            const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)lane * ts);
+            const uint32_t *srow = reinterpret_cast<const uint32_t *>((SEQ_SHARES ? buf0 : buf1) + (size_t)rlane * ts);
             // 'n' (0x6e) and 'N' (0x4e) differ in bit 5 only: one zero-byte test on (c | 0x20) ^ 'n'
             // flags both, bit 5 of the original byte tells them apart.  nlo = bit index of the first
             // lowercase n (NONE if none), anyN = whether an uppercase N occurs at all.
@@ -904,7 +982,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         // (staged kernels: no refill above, the next tile's pieces went out before the scan.  Tried and dropped: the cuts
         // stored a turn late, so that the next turn's wait for its pieces does not sit out this store -- 1-7 % slower)
         if (STAGE && scatter) index_settle(oidx);
-        if (active) out[scatter ? (uint64_t)oidx : r] = sk_cut_dev{five, three};
+        if (active && (!WIDE || lane < 32)) out[scatter ? (uint64_t)oidx : r] = sk_cut_dev{five, three};
         // this trip's LDS reads are complete (their results were consumed) before the next
         // trip may overwrite the buffer they came from
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -946,6 +1024,15 @@ sk_scan_tile_sorted_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
     if (scalar_load(a.sort_flags) == 0 || scalar_load(a.sort_flags + 1) != 0) return; // a uniform batch, or one with long reads
     sk_scan_tile_body<false, HAS_SEQ, true, 1, 0, false, 0, true, true>(qual, seq, counts, out, errword, a, reinterpret_cast<const sk_tile_dev *>(lists),
                                                                          reinterpret_cast<const uint32_t *>(perm), offsets);
+}
+
+// uniform medium reads (WIDE): tiles of 32 reads, a pair of lanes per read, windows of any width from 32 up
+template <bool HAS_SEQ>
+__global__ void __launch_bounds__(SK_TILE_THREADS, 2)
+sk_scan_tile_wide_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq, sk_cut_dev *__restrict__ out,
+                         unsigned long long *errword, sk_scan_args a)
+{
+    sk_scan_tile_body<true, HAS_SEQ, true, 1, 0, false, 0, true, false, true>(qual, seq, nullptr, out, errword, a, nullptr, nullptr, nullptr);
 }
 
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
@@ -1171,6 +1258,37 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     if (mfma) return launch(sk_scan_tile_any_kernel<true, false, true>);
     if (uniform) return launch(sk_scan_tile_any_kernel<true, false, false>);
     return launch(sk_scan_tile_any_kernel<false, false, true>);
+}
+
+// Uniform medium reads: the LDS bytes a wave needs for its 32-row image of reads of `read_len` bytes (0: not for this
+// kernel -- windows narrower than 32, or fewer than two waves to a CU)
+extern "C" __attribute__((visibility("hidden"))) uint32_t sk_wide_lds_bytes(uint32_t read_len)
+{
+    if (read_len / 10u < 32u || read_len > 4096u) return 0;
+    const uint32_t cpr = ((read_len + 15u) >> 4) | 1u;      // 16-byte chunks per image row (rag_pitch)
+    const uint32_t bytes = ((cpr + 1u) >> 1) * 1024u + SK_TILE_SLACK; // whole pieces of the loader
+    return bytes <= SK_LDS_PER_CU / 2u ? bytes : 0u;
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const uint8_t *qual, const uint8_t *seq, sk_cut_dev *out, unsigned long long *errword,
+                                     const sk_scan_args *a, int cu_count, hipStream_t stream)
+{
+    sk_scan_args aw = *a;
+    aw.buf_bytes = sk_wide_lds_bytes(a->read_len);
+    if (aw.buf_bytes == 0) return hipErrorInvalidValue;
+    int per_cu = (int)(SK_LDS_PER_CU / aw.buf_bytes);
+    if (per_cu > 16) per_cu = 16;
+    const uint64_t n_tiles = (a->n_reads + 31) >> 5;
+    uint64_t grid = (uint64_t)cu_count * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid == 0) return hipSuccess;
+    auto launch = [&](auto kern) {
+        const kernel_facts facts = prepare_kernel(kern);
+        if (facts.status != hipSuccess) return facts.status;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
+        return hipGetLastError();
+    };
+    return a->truncn ? launch(sk_scan_tile_wide_kernel<true>) : launch(sk_scan_tile_wide_kernel<false>);
 }
 
 // The sorted scan of a regrouped ragged batch.  a->buf_bytes = LDS bytes of a wave (sized for the longest read the
