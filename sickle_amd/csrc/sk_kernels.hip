@@ -106,7 +106,11 @@
 // The whole blocks need no band -- an all-ones matrix -- and their sum is carried from step to step in the accumulator
 // that also holds -T: entering block in (+ones), leaving block out (-ones).  Five MFMAs per 32 windows x 32 reads
 // whatever the width; two new fragments per step.
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false, bool WIDE = false>
+// WIDE == 2: tiles of 16 reads, FOUR lanes per read -- the 32 columns of the matrix are 16 reads x the two halves of
+// their windows (column n: read n mod 16, windows [0, H) for n < 16 and [H, ..) for the others, H a multiple of 32),
+// each half with its own state, the two joined when the windows are through.  Half the LDS per wave, so twice the
+// waves on a CU (a wave's MFMAs run under another wave's vector work), for the same MFMA count per byte.
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false, int WIDE = 0>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                   const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
@@ -115,8 +119,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 {
     static_assert(!SORT || (RAG && !UNIFORM && MFMA), "regrouped ragged batches: re-strided tiles, matrix path");
     static_assert(!WIDE || (RAG && UNIFORM && MFMA && !SORT), "medium reads: uniform batches, re-strided tiles, matrix path");
-    constexpr uint32_t ROWS = WIDE ? 32u : 64u; // reads per tile
-    constexpr int RSHIFT = WIDE ? 5 : 6;
+    constexpr uint32_t ROWS = WIDE == 2 ? 16u : WIDE ? 32u : 64u; // reads per tile
+    constexpr int RSHIFT = WIDE == 2 ? 4 : WIDE ? 5 : 6;
     static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
     static_assert(!MFMA || UNIFORM || RAG, "the matrix path needs one window width per tile");
     // MIXED (ragged batches): per-lane lengths in general, but a tile whose 64 reads have ONE length --
@@ -131,7 +135,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     constexpr bool SEQ_SHARES = HAS_SEQ && NBUF == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63;
-    const int rlane = WIDE ? (lane & 31) : lane; // the tile row (read) this lane works on
+    const int rlane = WIDE == 2 ? (lane & 15) : WIDE ? (lane & 31) : lane; // the tile row (read) this lane works on
+    const int part = WIDE == 2 ? (lane >> 4) & 1 : 0;                          // WIDE == 2: which half of the read's windows
     // readfirstlane: tells the compiler this is one value per wave, so that the tile index and
     // everything derived from it (addresses, piece counts, loop and switch conditions) live in
     // SGPRs and branch on the scalar unit instead of being carried through the vector ALU
@@ -419,7 +424,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     if (p + (uint32_t)u < cpr) piece(p + (uint32_t)u, ro[u], cq[u]);
             }
         } else {
-            const uint32_t pieces = WIDE ? (cpr + 1u) >> 1 : cpr; // (32 rows: the last piece's upper lanes fetch the tile's last bytes again)
+            const uint32_t pieces = WIDE == 2 ? (cpr + 3u) >> 2 : WIDE ? (cpr + 1u) >> 1 : cpr; // (32 / 16 rows: the last piece's upper lanes fetch the tile's last bytes again)
             for (uint32_t p = 0; p < pieces; ++p) {
                 uint32_t ro;
                 if (UNIFORM) ro = rr * stride;
@@ -658,10 +663,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 if (WIDE) {
                     // the two lanes of a read take its 8-dword groups in turns and add up what they found
                     int groups = 0;
-                    for (int g = half; 8 * g + 8 <= full; g += 2, ++groups) sad8(8 * g, sad);
+                    for (int g = WIDE == 2 ? lane >> 4 : half; 8 * g + 8 <= full; g += WIDE == 2 ? 4 : 2, ++groups) sad8(8 * g, sad);
                     sad -= (uint32_t)(32 * groups * range);
                     const sk_v2u both = __builtin_amdgcn_permlane32_swap(sad, sad, false, false);
                     sad = both[0] + both[1];
+                    if (WIDE == 2) sad += (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)sad);
                     k = full & ~7; // (the rest, below, by both alike)
                 } else {
                     for (; k + 8 <= full; k += 8) sad8(k, sad);
@@ -690,30 +696,51 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         // i0u / i1u: the 5' and the 3' window, NONE until found (a min() over the trips keeps
         // the first one, because later trips can only offer larger indices)
         uint32_t i0u = NONE, i1u = NONE;
+        uint32_t ltu = NONE; // WIDE == 2: the first window below the threshold in this lane's half of the windows, 5' window or not
         bool all_have5 = false; // wave-uniform
+        // WIDE == 2: this lane's windows are the nwin_l from window wofs on (the loop's `base` counts from there)
+        const int whalf = WIDE == 2 ? ((nwin + 63) >> 6) << 5 : 0;
+        const int wofs = WIDE == 2 ? part * whalf : 0;
+        const int nwin_l = WIDE == 2 ? (part ? max(nwin - whalf, 0) : min(nwin, whalf)) : nwin;
         // bit (31 - s) of M: window base+s is below the threshold
         auto step32 = [&](uint32_t M, int base) {
-            const int nv = nwin - base;
+            const int nv = nwin_l - base;
             const uint32_t vmask = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ~(~0u >> nv));
             const uint32_t lt = M & vmask;
+            const uint32_t at = (uint32_t)(base + wofs);
             uint32_t cand = lt; // with -x the 3' search starts at window 0 (trim.cpp:62)
             if (!a.no5 && !all_have5) {
                 const uint32_t ge = ~M & vmask;
-                i0u = min(i0u, __builtin_elementwise_add_sat(ffbh_or_none(ge), (uint32_t)base)); // trim.cpp:42
+                i0u = min(i0u, __builtin_elementwise_add_sat(ffbh_or_none(ge), at)); // trim.cpp:42
                 // windows of this trip strictly after i0: the low (base+31 - i0) bits, all 32 if
                 // i0 lies in an earlier trip, none while it is not found
-                const uint32_t width = __builtin_elementwise_sub_sat((uint32_t)(base + 31), i0u);
+                const uint32_t width = __builtin_elementwise_sub_sat(at + 31u, i0u);
                 const uint32_t low = (1u << (width & 31u)) - 1u;
                 cand = lt & (width >= 32u ? ~0u : low);
                 // once every lane has its 5' window, later trips need neither the search nor the mask
-                all_have5 = __builtin_amdgcn_ballot_w64(i0u == NONE) == 0;
+                if (WIDE != 2) all_have5 = __builtin_amdgcn_ballot_w64(i0u == NONE) == 0;
+                else ltu = min(ltu, __builtin_elementwise_add_sat(ffbh_or_none(lt), at));
             }
-            i1u = min(i1u, __builtin_elementwise_add_sat(ffbh_or_none(cand), (uint32_t)base)); // trim.cpp:61
+            i1u = min(i1u, __builtin_elementwise_add_sat(ffbh_or_none(cand), at)); // trim.cpp:61
+        };
+        // WIDE == 2: the two halves of a read's windows joined (lanes n and n ^ 16 hold them)
+        auto join_halves = [&]() {
+            const int other = (lane ^ 16) << 2;
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(other, (int)i0u), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(other, (int)i1u),
+                           ol = (uint32_t)__builtin_amdgcn_ds_bpermute(other, (int)ltu);
+            const uint32_t a0 = part ? o0 : i0u, a1 = part ? o1 : i1u;                          // the first half's
+            const uint32_t b0 = part ? i0u : o0, b1 = part ? i1u : o1, bl = part ? ltu : ol;   // the second half's
+            if (a.no5) {
+                i1u = a1 != NONE ? a1 : b1;
+            } else {
+                i0u = a0 != NONE ? a0 : b0;
+                i1u = a0 != NONE ? (a1 != NONE ? a1 : bl) : b1;
+            }
         };
 
         if (MFMA && (UNIFORM || tile_u)) {
             // lane (n = lane&31, half): 16 bytes of read 32g+n at positions 32*kb + 16*half
-            const uint8_t *frag0 = tile + (size_t)(lane & 31) * ts + 16 * half;
+            const uint8_t *frag0 = tile + (size_t)(WIDE == 2 ? rlane : lane & 31) * ts + 16 * half + wofs;
             const uint8_t *frag1 = frag0 + (size_t)32 * ts;
             auto load_frag = [](const uint8_t *p) -> sk_v4i {
                 const uint64_t lo = *reinterpret_cast<const uint64_t *>(p);
@@ -768,20 +795,22 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 // Two steps per turn; the fragments are read out of LDS two steps ahead and the matrix pipe runs one step
                 // ahead of the vector ALU: a step's five MFMAs are two dependent chains of 64 cycles a link, the sign
                 // collection of the step before runs underneath them.
+                const int nsteps = WIDE == 2 ? min(nwinmax, whalf) : nwinmax; // windows a lane walks
                 frags fa = fetch(0), fb = fa;
-                if (32 < nwinmax) fb = fetch(1);
+                if (32 < nsteps) fb = fetch(1);
                 sk_v16i da = sums(fa), db = da;
-                for (int base = 0; base < nwinmax; base += 64) {
+                for (int base = 0; base < nsteps; base += 64) {
                     const int st = base >> 5;
-                    const bool second = base + 32 < nwinmax, third = base + 64 < nwinmax;
+                    const bool second = base + 32 < nsteps, third = base + 64 < nsteps;
                     if (third) fa = fetch(st + 2);
                     if (second) db = sums(fb);
                     signs(da, base);
                     if (!second) break;
-                    if (base + 96 < nwinmax) fb = fetch(st + 3);
+                    if (base + 96 < nsteps) fb = fetch(st + 3);
                     if (third) da = sums(fa);
                     signs(db, base + 32);
                 }
+                if (WIDE == 2) join_halves();
             } else if (SEG == 2 || (SEG != 3 && !three_blocks)) { // w <= 33: positions base .. base+63, two trips per turn so that
                                  // the fragment registers alternate instead of being copied
                 sk_v4i qa0 = load_frag(frag0), qa1 = load_frag(frag1);
@@ -877,12 +906,23 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // bit index of the first hit RELATIVE to dword k (8*byte + 7 + 32*trip), NONE until found
             uint32_t h5 = ffbl_or_none(ge_flags(r5[0], cthr4) & (~0u << (8 * (i0 & 3))));
             uint32_t h3 = ffbl_or_none((ge_flags(r3[0], cthr4) ^ H4) & (~0u << (8 * (i1 & 3))));
-            for (int it = 1; it < trips; ++it) {
+            // (WIDE: the two / four lanes of a read take the dwords behind the first in turns and keep the earliest hit)
+            constexpr int SHARE = WIDE == 2 ? 4 : WIDE ? 2 : 1;
+            for (int it = 1 + (WIDE == 2 ? lane >> 4 : WIDE ? half : 0); it < trips; it += SHARE) {
                 const uint32_t g5 = ge_flags(r5[it], cthr4);
                 const uint32_t g3 = ge_flags(r3[it], cthr4) ^ H4;
-                const uint32_t rel = 32u * (uint32_t)it; // wave-uniform
+                const uint32_t rel = 32u * (uint32_t)it;
                 h5 = min(h5, __builtin_elementwise_add_sat(ffbl_or_none(g5), rel));
                 h3 = min(h3, __builtin_elementwise_add_sat(ffbl_or_none(g3), rel));
+            }
+            if (WIDE) {
+                const sk_v2u s5 = __builtin_amdgcn_permlane32_swap(h5, h5, false, false), s3 = __builtin_amdgcn_permlane32_swap(h3, h3, false, false);
+                h5 = min(s5[0], s5[1]);
+                h3 = min(s3[0], s3[1]);
+                if (WIDE == 2) {
+                    h5 = min(h5, (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)h5));
+                    h3 = min(h3, (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)h3));
+                }
             }
             if (have5 && h5 != NONE) five = 4 * k5 + (int)(h5 >> 3);
             if (done && h3 != NONE) three = 4 * k3 + (int)(h3 >> 3);
@@ -934,7 +974,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 if (UNIFORM || tile_u) {
                     const int full = (SORT ? min(Lfull, Lmax) : Lmax) >> 2;
                     const uint64_t *srow64 = reinterpret_cast<const uint64_t *>(srow);
-                    for (; k + 8 <= full; k += 8) {
+                    // (WIDE: the two / four lanes of a read take the 8-dword groups in turns; the rest below by all alike)
+                    constexpr int SHARE = WIDE == 2 ? 4 : WIDE ? 2 : 1;
+                    for (k = 8 * (WIDE == 2 ? lane >> 4 : WIDE ? half : 0); k + 8 <= full; k += 8 * SHARE) {
                         uint64_t x[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) x[u] = srow64[(k >> 1) + u];
@@ -944,8 +986,18 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                             n_step((uint32_t)(x[u] >> 32), 32u * (uint32_t)(k + 2 * u + 1));
                         }
                     }
+                    if (WIDE) k = full & ~7;
                 }
                 for (; 4 * k < Lmax; ++k) n_step(first_bytes(srow[k], L - 4 * k, 0u), 32u * (uint32_t)k);
+                if (WIDE) {
+                    const sk_v2u sn = __builtin_amdgcn_permlane32_swap(nlo, nlo, false, false), sa = __builtin_amdgcn_permlane32_swap(anyN, anyN, false, false);
+                    nlo = min(sn[0], sn[1]);
+                    anyN = sa[0] | sa[1];
+                    if (WIDE == 2) {
+                        nlo = min(nlo, (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)nlo));
+                        anyN |= (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)anyN);
+                    }
+                }
             }
             if (nlo != NONE) three = (int)(nlo >> 3) - 1;
             else if (anyN) three = -2;
@@ -982,7 +1034,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         // (staged kernels: no refill above, the next tile's pieces went out before the scan.  Tried and dropped: the cuts
         // stored a turn late, so that the next turn's wait for its pieces does not sit out this store -- 1-7 % slower)
         if (STAGE && scatter) index_settle(oidx);
-        if (active && (!WIDE || lane < 32)) out[scatter ? (uint64_t)oidx : r] = sk_cut_dev{five, three};
+        if (active && (!WIDE || lane < (int)ROWS)) out[scatter ? (uint64_t)oidx : r] = sk_cut_dev{five, three};
         // this trip's LDS reads are complete (their results were consumed) before the next
         // trip may overwrite the buffer they came from
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1027,12 +1079,12 @@ sk_scan_tile_sorted_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 }
 
 // uniform medium reads (WIDE): tiles of 32 reads, a pair of lanes per read, windows of any width from 32 up
-template <bool HAS_SEQ>
+template <bool HAS_SEQ, int WIDE>
 __global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_wide_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq, sk_cut_dev *__restrict__ out,
                          unsigned long long *errword, sk_scan_args a)
 {
-    sk_scan_tile_body<true, HAS_SEQ, true, 1, 0, false, 0, true, false, true>(qual, seq, nullptr, out, errword, a, nullptr, nullptr, nullptr);
+    sk_scan_tile_body<true, HAS_SEQ, true, 1, 0, false, 0, true, false, WIDE>(qual, seq, nullptr, out, errword, a, nullptr, nullptr, nullptr);
 }
 
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
@@ -1260,13 +1312,27 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     return launch(sk_scan_tile_any_kernel<false, false, true>);
 }
 
-// Uniform medium reads: the LDS bytes a wave needs for its 32-row image of reads of `read_len` bytes (0: not for this
-// kernel -- windows narrower than 32, or fewer than two waves to a CU)
+// Uniform medium reads: the LDS bytes a wave needs for its image of reads of `read_len` bytes (0: not for this kernel --
+// windows narrower than 32, or fewer than two waves to a CU)
+static uint32_t wide_image_bytes(uint32_t rows, uint32_t read_len)
+{
+    const uint32_t cpr = ((read_len + 15u) >> 4) | 1u;           // 16-byte chunks per image row (rag_pitch)
+    return ((rows * cpr + 63u) >> 6) * 1024u + SK_TILE_SLACK; // whole pieces of the loader
+}
+
+// 32 reads to a tile while five waves' images still fit a CU (reads up to ~940 bases), 16 beyond (measured: 600 bases 3.5
+// against 2.9 TB/s, 1 000 bases 2.2 against 2.7); SK_WIDE_ROWS=16|32 forces one (A/B runs)
+static uint32_t wide_rows(uint32_t read_len)
+{
+    static const uint32_t forced = [] { const char *e = getenv("SK_WIDE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    if (forced == 16u || forced == 32u) return forced;
+    return wide_image_bytes(32u, read_len) * 5u <= SK_LDS_PER_CU ? 32u : 16u;
+}
+
 extern "C" __attribute__((visibility("hidden"))) uint32_t sk_wide_lds_bytes(uint32_t read_len)
 {
-    if (read_len / 10u < 32u || read_len > 4096u) return 0;
-    const uint32_t cpr = ((read_len + 15u) >> 4) | 1u;      // 16-byte chunks per image row (rag_pitch)
-    const uint32_t bytes = ((cpr + 1u) >> 1) * 1024u + SK_TILE_SLACK; // whole pieces of the loader
+    if (read_len / 10u < 32u || read_len > 8192u) return 0;
+    const uint32_t bytes = wide_image_bytes(wide_rows(read_len), read_len);
     return bytes <= SK_LDS_PER_CU / 2u ? bytes : 0u;
 }
 
@@ -1278,7 +1344,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
     if (aw.buf_bytes == 0) return hipErrorInvalidValue;
     int per_cu = (int)(SK_LDS_PER_CU / aw.buf_bytes);
     if (per_cu > 16) per_cu = 16;
-    const uint64_t n_tiles = (a->n_reads + 31) >> 5;
+    const uint32_t rows = wide_rows(a->read_len);
+    const uint64_t n_tiles = (a->n_reads + rows - 1) / rows;
     uint64_t grid = (uint64_t)cu_count * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return hipSuccess;
@@ -1288,7 +1355,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
         return hipGetLastError();
     };
-    return a->truncn ? launch(sk_scan_tile_wide_kernel<true>) : launch(sk_scan_tile_wide_kernel<false>);
+    if (rows == 32) return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 1>) : launch(sk_scan_tile_wide_kernel<false, 1>);
+    return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 2>) : launch(sk_scan_tile_wide_kernel<false, 2>);
 }
 
 // The sorted scan of a regrouped ragged batch.  a->buf_bytes = LDS bytes of a wave (sized for the longest read the

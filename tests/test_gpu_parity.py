@@ -57,7 +57,10 @@ def test_kernel_selection():
     b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 0, 0, None, 1)
     assert capi.lib().sk_kernel_for(b) == 5  # ragged: the same kernel, per-lane lengths
     b = capi.Batch(q.ctypes.data, None, None, 600, 600, None, 10)
-    assert capi.lib().sk_kernel_for(b) == 2  # rows beyond the tile kernels: general kernel (teams of 16 lanes)
+    assert capi.lib().sk_kernel_for(b) == 8  # uniform medium reads: tiles of 32 / 16 reads, windows of any width on the matrix path
+    assert capi.lib().sk_kernel_name(8) == b"sk_scan_tile_wide_kernel"
+    b = capi.Batch(q.ctypes.data, None, None, 2600, 2600, None, 10)
+    assert capi.lib().sk_kernel_for(b) == 2  # beyond its range: general kernel (teams of 16 lanes)
     assert capi.lib().sk_kernel_name(7) == b"sk_scan_band_kernel"
     assert capi.lib().sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 5000, 5000, None, 10)
@@ -67,6 +70,27 @@ def test_kernel_selection():
     b = capi.Batch(q.ctypes.data, None, off.ctypes.data, 301, 0, None, 1)
     assert capi.lib().sk_kernel_for(b) == 5
     assert capi.lib().sk_kernel_name(6) == b"sk_scan_stream_kernel"
+
+
+@pytest.mark.gpu
+def test_uniform_medium_reads_soak(sk_ctx):
+    """tests/soak_wide.py: random uniform batches of 320 .. 2600 bases (edge lengths: multiples of 32 and of 10, the
+    switch from 32- to 16-read tiles, the end of the kernel's range), any stride, 1 .. 300 reads, every parameter, a
+    planted range error in every fourth -- host and device entry points against the oracle.  The kernel the library
+    selects must have been the medium-read tile kernel (8) among them."""
+    import soak_wide
+    checked, kernels = soak_wide.run(150, 2027, verbose=False)
+    assert checked == 300 and 8 in kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", ["16", "32"])
+def test_uniform_medium_reads_both_tile_heights(sk_ctx, rows, monkeypatch):
+    """SK_WIDE_ROWS forces 16- or 32-read tiles for every length the medium-read kernel takes."""
+    monkeypatch.setenv("SK_WIDE_ROWS", rows)
+    import subprocess, sys as _sys
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "soak_wide.py"), "60", "77"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-NAMES = ("n150", "u250", "u100", "seg", "seg_n", "seg_scatter", "packed150", "ragged150", "ragged_mix", "long", "long30k")
+NAMES = ("n150", "u250", "u100", "seg", "seg_n", "seg_scatter", "packed150", "ragged150", "ragged_mix", "u600", "u1000", "long", "long30k")
 
 
 def _quals(torch, shape, dev, seed):
@@ -85,6 +85,16 @@ def build(name, torch, capi, ctx, dev, stream, bench):
         return dict(launch=lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, stream=sp),
                     n_reads=n, algo_bytes=n * (L + 8), kernel="sk_scan_stream_kernel",
                     workload="30 kb reads back to back (stride 30000), %d reads: a wave per read, the read streamed through LDS" % n, keep=keep)
+    if name in ("u600", "u1000"):  # uniform medium reads back to back: rows beyond the 64-read tiles
+        L = int(name[1:])
+        n = 1_000_000_000 // L
+        q = _quals(torch, (n * L,), dev, 36)
+        out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        keep.extend([q, out])
+        kid = lib.sk_kernel_for(C.byref(capi.Batch(q.data_ptr(), None, None, L, L, None, n)))
+        return dict(launch=lambda: ctx.scan_device_async(p, q.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, stream=sp),
+                    n_reads=n, algo_bytes=n * (L + 8), kernel=lib.sk_kernel_name(kid).decode(),
+                    workload="%d bp reads back to back (stride %d), %d reads: tiles of %s reads, windows %d wide on the matrix path" % (L, L, n, "32" if L < 940 else "16", L // 10), keep=keep)
     if name == "packed150":
         d = uniform(150, 10_000_000, False, stride=150)
         d["workload"] = "150 bp reads packed back to back (stride 150): tiles re-strided into LDS, " + d["workload"]
