@@ -755,6 +755,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             // 0), lanes 32..63 reads 32..63 (group 1): after the swap s[0] = windows 0..15 of the
             // lane's own read, s[1] = windows 16..31
             auto collect = [&](const sk_v16i &d0, const sk_v16i &d1, int base) {
+                // (the quiet-step skip of the medium-read tiles, tried here for segmented and regrouped batches: with 64 reads to
+                // a tile a trip without a single sum below the threshold is rare, the test costs more than it saves)
                 uint32_t p0 = 0, p1 = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)d0[i], 31);
