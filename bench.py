@@ -148,13 +148,15 @@ def run_variants(torch, capi, ctx, device, stream, names, reps, full=False):
         try:
             v = variants.build(name, torch, capi, ctx, device, stream, me)
             torch.cuda.synchronize(device)
-            avg, lo, hi = time_launches(torch, stream, v["launch"], lambda: ctx.scan_device_finish(stream.cuda_stream), reps, 10)
+            # (building a variant's batch leaves the device idle long enough for its clocks to drop: 100 untimed launches first
+            # -- with 10, `seg` read 0.46 of peak where 300 launches in a row say 0.55-0.61)
+            avg, lo, hi = time_launches(torch, stream, v["launch"], lambda: ctx.scan_device_finish(stream.cuda_stream), reps, 100)
             gbs = v["algo_bytes"] / (avg * 1e-3) / 1e9
             out[name] = {"k": short_kernel(v["kernel"]), "ms": r4(avg), "GBps": r4(gbs), "frac": r4(gbs / HBM_PEAK_GBS)}
             if full:
                 out[name].update({"workload": v["workload"], "kernel": v["kernel"], "reads": v["n_reads"], "kernel_ms_avg": avg, "kernel_ms_min": lo, "kernel_ms_max": hi,
                                   "achieved": gbs, "unit": "GB/s",
-                                  "algorithmic_bytes_per_launch": v["algo_bytes"], "scans_in_run": reps + 10})
+                                  "algorithmic_bytes_per_launch": v["algo_bytes"], "scans_in_run": reps + 100})
             del v
             torch.cuda.empty_cache()
         except Exception as e:  # a failing variant must not cost the headline line

@@ -1280,8 +1280,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
             return hipGetLastError();
         };
         hipError_t e;
-        // no -n, windows <= 33, rows up to 320 bytes: the next tile waits in the wave's registers (SK_SEG_STAGE=0: A/B runs)
-        static const bool seg_stage = [] { const char *v = getenv("SK_SEG_STAGE"); return !(v && *v == '0'); }();
+        // no -n, windows <= 33, rows up to 320 bytes: the next tile can wait in the wave's registers (SK_SEG_STAGE=1).  Not the
+        // default: on the mixed batch with the realistic quality model it is 3 % faster than the LDS-DMA kernel (162 against
+        // 167.5 us), on the bench's `seg` batch 10 % slower (0.180 against 0.162 ms) -- see DESIGN 4.1.1
+        static const bool seg_stage = [] { const char *v = getenv("SK_SEG_STAGE"); return v && *v == '1'; }();
         if (seg_stage && !a->truncn && !k.wide && k.max_stride <= 320u)
             e = k.max_stride <= 160u ? launch(sk_scan_seg_staged_kernel<10>, 12) : launch(sk_scan_seg_staged_kernel<20>, 8);
         else if (a->truncn) e = k.wide ? launch(sk_scan_tile_kernel<true, true, true, 1, 0, 3>) : launch(sk_scan_tile_kernel<true, true, true, 1, 0, 2>);

@@ -73,6 +73,16 @@ def test_kernel_selection():
 
 
 @pytest.mark.gpu
+def test_segmented_tiles_staged_through_registers(sk_ctx):
+    """SK_SEG_STAGE=1 (read once per process, so a child): the register-staged variant of the segmented kernel --
+    built, not the default -- through tests/soak_tiles.py."""
+    import subprocess, sys as _sys
+    env = dict(os.environ, SK_SEG_STAGE="1")
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "soak_tiles.py"), "150", "31"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_uniform_medium_reads_soak(sk_ctx):
     """tests/soak_wide.py: random uniform batches of 320 .. 2600 bases (edge lengths: multiples of 32 and of 10, the
     switch from 32- to 16-read tiles, the end of the kernel's range), any stride, 1 .. 300 reads, every parameter, a

@@ -6,7 +6,7 @@
 set -o pipefail
 TAG=${1:-r02}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-VARIANTS=${*:-"n150 u250 u100 seg seg_n seg_scatter packed150 ragged150 ragged_mix long long30k"}
+VARIANTS=${*:-"n150 u250 u100 seg seg_n seg_scatter packed150 ragged150 ragged_mix u600 u1000 long long30k"}
 cd /tmp && export TMPDIR=/tmp
 for V in $VARIANTS; do
   OUT=$ROOT/gpurun_out/prof_$TAG/$V
