@@ -40,8 +40,9 @@
  *                 SK_TILE_MAX_STRIDE, base pointers 16-byte aligned, stride/8 ODD (152, 104, 264
  *                 ...: the rows then spread over all LDS banks; stride/8 even still works, slower).
  *                 Any other stride <= SK_TILE_MAX_STRIDE or alignment (e.g. reads packed back to
- *                 back, stride == read_len) is re-strided like a ragged batch; longer rows go
- *                 through the general kernel.
+ *                 back, stride == read_len) is re-strided like a ragged batch; longer rows: one
+ *                 length (lengths == NULL) of up to ~1900 bases keeps the tile kernel with 32 or 16
+ *                 reads to a tile (round 3), anything else goes through the general kernels.
  *   segmented   : tiles != NULL (offsets and lengths NULL).  The caller has grouped the reads
  *                 by length: tile t holds `rows` (<= 64) reads of `read_len` bytes each at
  *                 qual[byte_off + i*stride] (stride % 8 == 0, byte_off % 16 == 0), and slot
@@ -212,9 +213,11 @@ int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
- * 2 = general, medium reads (teams of 16 lanes per read, up to a longest read of 4096), 6 = general, long reads (a
+ * 8 = uniform medium reads (fixed stride, one length of ~505 .. 1900 bases: tiles of 32 or 16 reads, a pair / four lanes
+ * per read, windows of any width on the matrix path), 2 = general, medium reads (teams of 16 lanes per read, up to a
+ * longest read of 4096: ragged medium reads, uniform ones beyond 8's range), 6 = general, long reads (a
  * wave per read with the read streamed through LDS), 3 = tiled over a segmented batch, 4 = tiled with the tile
- * staged through registers (equal lengths, no sequence buffer, row stride 72..160), 5 = tiled with rows re-strided
+ * staged through registers (equal lengths, no sequence buffer, row stride 72..320), 5 = tiled with rows re-strided
  * on the way into LDS (packed / misaligned fixed stride, ragged; a ragged batch of mixed lengths is regrouped on
  * the device first -- the device decides, so the answer stays 5).  7 = round 3's matrix-pipe wave-per-read kernel
  * for medium reads (sk_band.hip): built and parity-tested, no shape selects it (SK_GENERAL=band forces it; it is
