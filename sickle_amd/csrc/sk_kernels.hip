@@ -809,8 +809,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 // ahead of the vector ALU: a step's five MFMAs are two dependent chains of 64 cycles a link, the sign
                 // collection of the step before runs underneath them.
                 // (Tried: leaving the walk once every lane has its 3' window.  Every variant of it -- break, a shrinking bound,
-                // with and without the next step's MFMAs in flight -- gave wrong cuts in tests/soak_wide.py although the
-                // state it tests only ever moves one way; not understood, so not done.)
+                // with and without the next step's MFMAs in flight -- gave wrong cuts in tests/soak_wide.py.  A build that
+                // only PRINTS the state after every turn shows it right (no lane with a 3' window, cuts equal to the
+                // oracle's); the same build with the exit taken shows window 14 "below the threshold" for every read after
+                // the FIRST turn: the exit changes the code generated for the steps before it.  Compiler or hazard, not
+                // the algorithm -- not pursued, not done.)
                 const int nsteps = WIDE == 2 ? min(nwinmax, whalf) : nwinmax; // windows a lane walks
                 frags fa = fetch(0), fb = fa;
                 if (32 < nsteps) fb = fetch(1);
