@@ -208,10 +208,10 @@ uint32_t rag_buf_bytes(uint64_t max_len, bool uniform)
 
 // which path a batch takes: 3 segmented, 1 tiled (aligned rows), 5 tiled (rows at any address),
 // 2 general kernel only
-// The general kernels, by the caller's longest-read hint: a wave per read with the read resident in LDS and its
-// window sums from the matrix pipe (sk_band.hip) up to SK_STREAM_MIN bytes, the streaming wave-per-read kernel
-// (sk_stream.hip) beyond and when there is no hint.  SK_GENERAL=band|team|stream forces one (diagnostics, tests;
-// team = round 2's teams of 16 lanes on the vector ALU, sk_team.hip, which nothing selects any more).
+// The general kernels, by the caller's longest-read hint: teams of 16 lanes per read (sk_team.hip) up to SK_STREAM_MIN
+// bytes, the streaming wave-per-read kernel (sk_stream.hip) beyond and when there is no hint.  SK_GENERAL=band|team|stream
+// forces one (diagnostics, tests; band = round 3's wave-per-read kernel with matrix-pipe window sums, sk_band.hip:
+// parity-green, not faster than the teams, selected by nothing).  Uniform medium reads do not come here: wide_takes().
 constexpr uint64_t SK_STREAM_MIN_DEFAULT = 4096;
 hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_t *offsets, const uint32_t *lengths, sk_cut_dev *out,
                           unsigned long long *errword, const sk_scan_args *a, uint64_t max_len, int cu_count, hipStream_t stream)
@@ -219,7 +219,6 @@ hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_
     const char *force = getenv("SK_GENERAL");
     static const uint64_t stream_min = [] { const char *e = getenv("SK_STREAM_MIN"); return e ? (uint64_t)atoll(e) : SK_STREAM_MIN_DEFAULT; }();
     const bool use_stream = force ? force[0] == 's' : (max_len == 0 || max_len > stream_min);
-    // (until the band kernel is the faster one at every medium length, the teams stay the default)
     if (!use_stream && !(force && force[0] == 'b')) return sk_launch_team(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);
     return use_stream ? sk_launch_stream(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream)
                       : sk_launch_band(qual, seq, offsets, lengths, out, errword, a, max_len, cu_count, stream);

@@ -457,10 +457,11 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         return (SEG || p == STAGE - 1) ? min(off, bytes - 16u) : off;
     };
 
-    // Which tiles a wave takes: tile t, then t + (number of waves), ... -- except in segmented batches, where a
-    // wave takes SEG_CHUNK consecutive tiles at a time.  There the tiles are sorted by length, and with single
-    // steps every wave met a new length at every tile (its tiles lie `waves` apart) and rebuilt the band matrix
-    // each time (set_length: ~150 instructions against ~600 for the tile's scan); a chunk shares one length.
+    // Which tiles a wave takes: tile t, then t + (number of waves), ...: the launch sweeps the batch front to back (taking
+    // a length-sorted list from both ends at once, for balanced tile sizes per CU, is 10-15 % slower).  Segmented batches
+    // can take SEG_CHUNK consecutive tiles at a time (seg_chunk_shift; round 2's default was 4: with single steps every
+    // wave met a new length at every tile and REBUILT the band matrix, ~150 instructions against ~600 for the scan).
+    // Since the band comes from a table, prefetched, single steps are the default again: chunks cost 3-5 % at long rows.
     // (SORT: one tile at a time -- with chunks of 4 a list's 256 waves have 7 windows open at once, 10 MB, and the XCD's
     // L2 no longer holds the lines two neighbours share: 1187 against 946 MB fetched per scan of 790 MB)
     const uint64_t SEG_CHUNK = SORT ? 1ull : 1ull << a.seg_chunk_shift;
