@@ -80,6 +80,15 @@ def test_segmented_tiles_staged_through_registers(sk_ctx):
     env = dict(os.environ, SK_SEG_STAGE="1")
     r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "soak_tiles.py"), "150", "31"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "seg_many_tiles.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "seg many tiles ok: 4 scans" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_segmented_batch_many_tiles_per_wave(sk_ctx):
+    """tests/seg_many_tiles.py with the default (LDS-DMA) segmented kernel: 300 000 reads of 75..301 bases in > 4 096 tiles."""
+    import seg_many_tiles
+    assert seg_many_tiles.run() == 4
 
 
 @pytest.mark.gpu
@@ -91,6 +100,38 @@ def test_uniform_medium_reads_soak(sk_ctx):
     import soak_wide
     checked, kernels = soak_wide.run(150, 2027, verbose=False)
     assert checked == 300 and 8 in kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,n", [(600, 150_000), (1000, 120_000), (1500, 80_000)])
+def test_uniform_medium_reads_many_tiles_per_wave(sk_ctx, L, n):
+    """More tiles than the launch has waves (2 304 .. 4 096): every wave goes round its loop several times -- refill
+    after the scan, the next tile's first step behind the last one's state -- which tests/soak_wide.py's small batches
+    never do.  Device-resident, with and without -n, 3' declines at random places, some reads bad from the start, some
+    good to the end; against the oracle."""
+    import torch
+    rng = np.random.default_rng(L)
+    q = rng.integers(60, 74, size=(n, L), dtype=np.uint8)
+    cut = rng.integers(0, L + L // 4, size=n)
+    cols = np.arange(L)[None, :]
+    q[cols >= cut[:, None]] -= 25
+    head = rng.integers(0, 60, size=n)
+    q[(cols < head[:, None]) & (rng.random(n) < 0.3)[:, None]] = 35
+    seq = rng.choice(np.frombuffer(b"ACGT" * 2000 + b"Nn", dtype=np.uint8), size=(n, L))
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    dq, ds = torch.from_numpy(q.reshape(-1)).cuda(), torch.from_numpy(seq.reshape(-1)).cuda()
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    assert capi.lib().sk_kernel_for(capi.Batch(dq.data_ptr(), None, None, L, L, None, n)) == 8
+    for tn in (False, True):
+        p, po = both_params("sanger", 20, 20, False, tn)
+        want, err = ob.oracle_trim_batch(po, q.reshape(-1), seq.reshape(-1), offsets=offs, threads=8)
+        assert err is None
+        out.fill_(-7)
+        sk_ctx.scan_device_async(p, dq.data_ptr(), out.data_ptr(), n, stride=L, read_len=L, seq_ptr=ds.data_ptr() if tn else None)
+        sk_ctx.scan_device_finish()
+        got = out.cpu().numpy()
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (L, tn, bad[:5], got[bad[:5]], want[bad[:5]])
 
 
 @pytest.mark.gpu
