@@ -231,7 +231,7 @@ bool wide_takes(const sk_batch *b)
 {
     if (b->offsets || b->lengths || b->tiles || getenv("SK_GENERAL")) return false;
     static const uint32_t wide_max = [] { const char *e = getenv("SK_WIDE_MAX"); return e ? (uint32_t)atoi(e) : 1900u; }();
-    return b->read_len <= wide_max && sk_wide_lds_bytes(b->read_len) != 0;
+    return b->read_len <= wide_max && b->stride < (1u << 24) && sk_wide_lds_bytes(b->read_len) != 0; // (the loader's 24-bit row offsets)
 }
 
 int path_of(const sk_batch *b)

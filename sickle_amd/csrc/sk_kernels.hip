@@ -430,7 +430,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             const uint32_t pieces = WIDE == 2 ? (cpr + 3u) >> 2 : WIDE ? (cpr + 1u) >> 1 : cpr; // (32 / 16 rows: the last piece's upper lanes fetch the tile's last bytes again)
             for (uint32_t p = 0; p < pieces; ++p) {
                 uint32_t ro;
-                if (UNIFORM) ro = rr * stride;
+                if (UNIFORM) ro = WIDE ? __umul24(rr, stride) : rr * stride; // (WIDE: stride < 2^24, wide_takes())
                 else if (v.uni) ro = rr * (uint32_t)__builtin_amdgcn_readfirstlane(v.len); // equal lengths: rows len apart
                 else ro = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rr << 2), (int)v.rowoff);
                 piece(p, ro, cc);
@@ -649,10 +649,19 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         uint32_t sad = 0;
         {
             const uint64_t *row64 = reinterpret_cast<const uint64_t *>(row);
-            auto sad8 = [&](int k, uint32_t &acc) { // dwords k .. k+7: 4 x ds_read_b64 in flight, then 16 SADs
+            auto sad8 = [&](int k, uint32_t &acc) { // dwords k .. k+7: 4 x ds_read_b64 (re-strided images: 2 x ds_read_b128) in flight, then 16 SADs
                 uint64_t x[4];
+                if (RAG) {
+                    const sk_v4u *r128 = reinterpret_cast<const sk_v4u *>(__builtin_assume_aligned(row + k, 16));
+                    const sk_v4u lo = r128[0], hi = r128[1];
+                    x[0] = ((uint64_t)lo[1] << 32) | lo[0];
+                    x[1] = ((uint64_t)lo[3] << 32) | lo[2];
+                    x[2] = ((uint64_t)hi[1] << 32) | hi[0];
+                    x[3] = ((uint64_t)hi[3] << 32) | hi[2];
+                } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = row64[(k >> 1) + u];
+                    for (int u = 0; u < 4; ++u) x[u] = row64[(k >> 1) + u];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     acc = __builtin_amdgcn_sad_u8((uint32_t)x[u], min4, acc);
@@ -747,6 +756,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             const uint8_t *frag0 = tile + (size_t)(WIDE == 2 ? rlane : lane & 31) * ts + 16 * half + wofs;
             const uint8_t *frag1 = frag0 + (size_t)32 * ts;
             auto load_frag = [](const uint8_t *p) -> sk_v4i {
+                // re-strided images have rows at a pitch of 16 x odd bytes: ONE 16-byte read, 16 lanes to the 64 banks
+                // (two 8-byte reads fall two lanes to a bank pair there); the strided layouts' rows are 8-byte aligned
+                if (RAG) return *reinterpret_cast<const sk_v4i *>(__builtin_assume_aligned(p, 16));
                 const uint64_t lo = *reinterpret_cast<const uint64_t *>(p);
                 const uint64_t hi = *reinterpret_cast<const uint64_t *>(p + 8);
                 sk_v4i f = {(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
