@@ -61,6 +61,8 @@ def test_kernel_selection():
     assert capi.lib().sk_kernel_name(8) == b"sk_scan_tile_wide_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 2600, 2600, None, 10)
     assert capi.lib().sk_kernel_for(b) == 2  # beyond its range: general kernel (teams of 16 lanes)
+    b = capi.Batch(q.ctypes.data, None, None, 1 << 24, 1000, None, 2)
+    assert capi.lib().sk_kernel_for(b) == 2  # rows 16 MiB apart: beyond the loader's 24-bit row offsets
     assert capi.lib().sk_kernel_name(7) == b"sk_scan_band_kernel"
     assert capi.lib().sk_kernel_name(5) == b"sk_scan_tile_any_kernel"
     b = capi.Batch(q.ctypes.data, None, None, 5000, 5000, None, 10)
