@@ -491,8 +491,10 @@ void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
     // reads are grouped by length (counting sort) into tiles of <= 64 equal-length rows, each group
     // at its own stride, described to the device by one sk_tile per tile; every tile is uniform
     // inside, so the batch stays on the same fast path with no padding to the longest read, and
-    // the device scatters the cuts back to input order (out_index).  Anything longer: packed back
-    // to back with an offsets array -> the general (wave-per-read) kernel.
+    // the device scatters the cuts back to input order (out_index).  Longer reads of ONE length (up
+    // to 4 096 bases): back to back at a fixed stride = their length -- the library's medium-read tiles
+    // take those up to ~1 900 bases on the matrix path, its general kernels the rest.  Anything else:
+    // packed back to back with an offsets array -> the general kernels.
     size_t total_len = 0, max_len = 0;
     bool uniform = true;
     const size_t len0 = n ? reads[0].qual.length() : 0;
@@ -530,6 +532,7 @@ void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
     };
     const bool tiled = n > 0 && max_len > 0 && stride_for(max_len) <= SK_TILE_MAX_STRIDE;
     const bool segmented = tiled && !uniform;
+    const bool medium = !tiled && uniform && n > 0 && len0 > 0 && len0 <= 4096;
     const bool need_seq = trunc_n != 0;
 
     sk_batch b;
@@ -592,6 +595,16 @@ void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
             }
         });
         b.stride = (uint32_t)stride;
+        b.read_len = (uint32_t)len0;
+    } else if (medium) {
+        grow(ctx, s, total_len, n, need_seq);
+        pool.parallel_for(n, parts, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; ++i) {
+                memcpy(s.qual + i * len0, reads[i].qual.data(), len0);
+                if (need_seq) memcpy(s.seq + i * len0, reads[i].seq.data(), len0);
+            }
+        });
+        b.stride = (uint32_t)len0;
         b.read_len = (uint32_t)len0;
     } else {
         grow(ctx, s, total_len, n, need_seq);

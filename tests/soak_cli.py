@@ -51,7 +51,9 @@ def run(iters=20, seed=1, verbose=True):
             shape = it % 4
             inter = bool(it % 2)
             if shape == 0:
-                L = int(rng.choice([20, 36, 75, 100, 150, 151, 250, 301]))
+                L = int(rng.choice([20, 36, 75, 100, 150, 151, 250, 301, 600, 1000, 1500, 2600]))  # (the last four: one length beyond the 64-read tiles)
+                if L >= 600:
+                    n = min(n, 500)
                 l1 = l2 = np.full(n, L)
             elif shape == 1:
                 l1, l2 = rng.integers(1, 400, size=n), rng.integers(1, 400, size=n)
