@@ -56,14 +56,14 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
     __shared__ uint32_t cnt_w[NW][NC]; // per wave and class: count, then the rank its first read of the class gets
     __shared__ uint32_t hist[NC], tbase[NC], gbase, tmax[NT], tmin[NT];
     __shared__ uint32_t rel[W + 1]; // the window's offsets relative to its first (loaded lane by lane, read 9 per thread)
-    if (counts[8] == 0) return; // a batch of one length (as far as the sample saw): nothing to regroup
     const int t = threadIdx.x, wave = t >> 6;
     const uint64_t widx = blockIdx.x, r0 = widx * W;
+    const uint64_t wstart = offsets[r0]; // (issued with the verdict's load, not behind it)
+    if (counts[8] == 0) return; // a batch of one length (as far as the sample saw): nothing to regroup
     const uint32_t m = (uint32_t)min((uint64_t)W, n_reads - r0);
     for (int i = t; i < NW * NC; i += THREADS) (&cnt_w[0][0])[i] = 0;
     if (t < NT) tmax[t] = 0, tmin[t] = 0xffffu;
     __syncthreads();
-    const uint64_t wstart = offsets[r0];
     uint32_t nlong = 0;
 #pragma unroll
     for (int i = 0; i <= PER; ++i) {
@@ -106,6 +106,7 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
     __syncthreads();
     // per class: the waves' counts -> where each wave's reads of the class begin; then exclusive prefixes over the 64
     // classes: tiles (one wave)
+    uint32_t g_mine = 0;
     if (t < NC) {
         uint32_t run = 0;
 #pragma unroll
@@ -123,23 +124,33 @@ sk_sort_windows_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, u
             if (t >= d) q += uq;
         }
         tbase[t] = q - nt;
-        if (t == NC - 1) gbase = atomicAdd(&counts[widx & 7u], q); // the window's tiles get their places in the list of XCD widx mod 8
+        // the window's tiles get their places in the list of XCD widx mod 8 -- the atomic's round trip runs under the ranking below
+        if (t == NC - 1) g_mine = atomicAdd(&counts[widx & 7u], q);
     }
     if (nlong) atomicAdd(&counts[9], nlong);
+    __syncthreads();
+    uint32_t rank[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        rank[i] = 0;
+        if (cl[i] != 255) {
+            rank[i] = atomicAdd(&cnt_w[wave][cl[i]], 1u); // the read's place in its class: tile rank / 64, lane rank % 64
+            const uint32_t ltile = tbase[cl[i]] + (rank[i] >> 6);
+            atomicMax(&tmax[ltile], (uint32_t)ln[i]); // the longest and the shortest read of the tile: the scan sizes its image
+            atomicMin(&tmin[ltile], (uint32_t)ln[i]); // and its unmasked loops by them, without a reduction over the lanes
+        }
+    }
+    if (t == NC - 1) gbase = g_mine;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t k = k0 + (uint32_t)i;
         if (cl[i] != 255) {
-            const uint32_t rank = atomicAdd(&cnt_w[wave][cl[i]], 1u); // the read's place in its class: tile rank / 64, lane rank % 64
-            const uint32_t ltile = tbase[cl[i]] + (rank >> 6), tile = gbase + ltile;
-            atomicMax(&tmax[ltile], (uint32_t)ln[i]); // the longest and the shortest read of the tile: the scan sizes its image
-            atomicMin(&tmin[ltile], (uint32_t)ln[i]); // and its unmasked loops by them, without a reduction over the lanes
+            const uint32_t tile = gbase + tbase[cl[i]] + (rank[i] >> 6);
             if (tile < list_cap)
-                perm[((size_t)(widx & 7u) * list_cap + tile) * 64u + (rank & 63u)] = (uint64_t)ro[i] | ((uint64_t)ln[i] << 32) | ((uint64_t)k << 48);
+                perm[((size_t)(widx & 7u) * list_cap + tile) * 64u + (rank[i] & 63u)] = (uint64_t)ro[i] | ((uint64_t)ln[i] << 32) | ((uint64_t)k << 48);
         }
     }
-    __syncthreads();
     if (t < NC) {
         const uint32_t cnt = hist[t], nt = (cnt + 63u) >> 6;
         unsigned long long *dst = lists + ((size_t)(widx & 7u) * list_cap + gbase + tbase[t]) * 4u;
