@@ -113,7 +113,7 @@
 // their windows (column n: read n mod 16, windows [0, H) for n < 16 and [H, ..) for the others, H a multiple of 32),
 // each half with its own state, the two joined when the windows are through.  Half the LDS per wave, so twice the
 // waves on a CU (a wave's MFMAs run under another wave's vector work), for the same MFMA count per byte.
-template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false, int WIDE = 0>
+template <bool UNIFORM, bool HAS_SEQ, bool MFMA, int NBUF, int ABLATE, int SEG, int STAGE, bool RAG, bool SORT = false, int WIDE = 0, int WSTAGE = 0>
 __device__ __forceinline__ void
 sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq,
                   const uint32_t *__restrict__ lengths, sk_cut_dev *__restrict__ out,
@@ -122,6 +122,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 {
     static_assert(!SORT || (RAG && !UNIFORM && MFMA), "regrouped ragged batches: re-strided tiles, matrix path");
     static_assert(!WIDE || (RAG && UNIFORM && MFMA && !SORT), "medium reads: uniform batches, re-strided tiles, matrix path");
+    static_assert(!WSTAGE || (WIDE && !HAS_SEQ), "the medium-read tiles' register stage: without -n");
     constexpr uint32_t ROWS = WIDE == 2 ? 16u : WIDE ? 32u : 64u; // reads per tile
     constexpr int RSHIFT = WIDE == 2 ? 4 : WIDE ? 5 : 6;
     static_assert(!RAG || (NBUF == 1 && !SEG && STAGE == 0 && ABLATE == 0), "re-strided tiles: one buffer, LDS-DMA");
@@ -443,6 +444,45 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         else tile_to_lds(base + v.off, dst, v.bytes, lane);
     };
 
+    // WSTAGE (medium-read tiles without -n whose image has at most WSTAGE 1 KiB pieces, rows 4-byte aligned): the NEXT
+    // tile waits in the wave's registers -- plain 16-byte loads at the re-striding loader's addresses, in flight while
+    // this tile is scanned, written to LDS (same image) at the top of the next turn.  Every full tile of the launch has
+    // the same shape, so a lane's source offsets relative to its tile are computed ONCE (the DMA loader spends ~12 vector
+    // instructions a piece on them, tile after tile); the wave no longer waits for its tile after every scan (43 % of
+    // its cycles at 1 000 bases), and the loads are plain ones.  The batch's last tiles (fewer rows, or chunks that could
+    // leave the caller's buffer) come in by LDS-DMA as before.
+    typedef uint32_t sk_v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t wso[WSTAGE ? WSTAGE : 1];
+    sk_v4u wst[WSTAGE ? WSTAGE : 1];
+    const uint32_t wpieces = WSTAGE ? (ROWS * (rag_pitch<true>(a.read_len) / 16u) + 63u) >> 6 : 0u;
+    if (WSTAGE) {
+        const uint32_t cpr = rag_pitch<true>(a.read_len) / 16u, qd = 64u / cpr, rd = 64u % cpr;
+        const uint32_t lim = (ROWS - 1u) * stride + a.read_len - 1u;
+        uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
+#pragma unroll
+        for (int p = 0; p < WSTAGE; ++p) {
+            wso[p] = min(__umul24(rr, stride) + 16u * cc, lim);
+            cc += rd;
+            rr += qd;
+            if (cc >= cpr) {
+                cc -= cpr;
+                ++rr;
+            }
+        }
+    }
+    auto wstage_ok = [&](const sk_tile_view &v) -> bool { return WSTAGE && v.rows == ROWS && v.off + (uint64_t)v.bytes + 16u <= batch_end; };
+    auto wstage_load = [&](const sk_tile_view &v) {
+        const uint8_t *src = qual + v.off;
+#pragma unroll
+        for (int p = 0; p < WSTAGE; ++p) wst[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u_a4 *>(src + wso[p]));
+    };
+    auto wstage_write = [&]() {
+#pragma unroll
+        for (int p = 0; p < WSTAGE; ++p)
+            if ((uint32_t)p < wpieces) *reinterpret_cast<sk_v4u *>(buf0 + (uint32_t)p * 1024u + (uint32_t)lane * 16u) = wst[p];
+    };
+    bool w_cur = false, w_nxt = false;
+
     // register stage: piece p of a FULL tile (64 rows; 64*stride bytes, a multiple of 512) is the
     // 16 bytes per lane at p KiB; STAGE = the number of pieces, the last one may be a half (its
     // upper lanes repeat the tile's last 16 bytes: same data to the same place, no predication).
@@ -483,6 +523,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
 #pragma unroll
         for (int p = 0; p < STAGE; ++p)
             stage[p] = __builtin_nontemporal_load(reinterpret_cast<const sk_v4u *>(qual + cur.off + stage_off(p, cb)));
+    } else if (wstage_ok(cur)) {
+        wstage_load(cur);
+        w_cur = true;
     } else if (cur.take) {
         load_tile(qual, buf0, cur);
     }
@@ -535,7 +578,8 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             if (more) raw = sort_issue(tn); // looked at when this turn's scan is over
         } else if (SEQ_SHARES || RAG) {
             tile = buf0;
-            wait_vmcnt(0); // Q(t)
+            if (WSTAGE && w_cur) wstage_write(); // (the compiler waits for the registers)
+            else wait_vmcnt(0);                  // Q(t)
         } else if (HAS_SEQ) {
             tile = buf0;
             // outstanding, oldest first: Q(t), S(t) [, store(t-1) before them]
@@ -596,6 +640,10 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             parity ^= 1;
         }
         if (!PROBE_EARLY && !SORT && more) nxt = probe(tn);
+        if (WSTAGE) {
+            w_nxt = more && wstage_ok(nxt);
+            if (w_nxt) wstage_load(nxt);
+        }
         if (SEG) ahead = fetch_desc(min(next_tile(tn), n_tiles - 1));
         if (SEG && more) probe_index(nxt);
         if (SEG && more && width_of(nxt.len) != wu) band_next = band_fetch(width_of(nxt.len));
@@ -1052,8 +1100,9 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 nxt = sort_finish(raw);
                 if (next_w != wu && next_w != 0) band_next = band_fetch(next_w);
             }
-            if (more && nxt.take) load_tile(qual, buf0, nxt);
+            if (more && nxt.take && !(WSTAGE && w_nxt)) load_tile(qual, buf0, nxt);
         }
+        if (WSTAGE) w_cur = w_nxt;
 #if SK_TAIL_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1111,12 +1160,12 @@ sk_scan_tile_sorted_kernel(const uint8_t *__restrict__ qual, const uint8_t *__re
 }
 
 // uniform medium reads (WIDE): tiles of 32 reads, a pair of lanes per read, windows of any width from 32 up
-template <bool HAS_SEQ, int WIDE>
+template <bool HAS_SEQ, int WIDE, int WSTAGE = 0>
 __global__ void __launch_bounds__(SK_TILE_THREADS, 2)
 sk_scan_tile_wide_kernel(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ seq, sk_cut_dev *__restrict__ out,
                          unsigned long long *errword, sk_scan_args a)
 {
-    sk_scan_tile_body<true, HAS_SEQ, true, 1, 0, false, 0, true, false, WIDE>(qual, seq, nullptr, out, errword, a, nullptr, nullptr, nullptr);
+    sk_scan_tile_body<true, HAS_SEQ, true, 1, 0, false, 0, true, false, WIDE, WSTAGE>(qual, seq, nullptr, out, errword, a, nullptr, nullptr, nullptr);
 }
 
 // the register-staged variant (STAGE = KiB pieces per tile = ceil(stride / 16)): the registers of a
@@ -1354,6 +1403,7 @@ static uint32_t wide_image_bytes(uint32_t rows, uint32_t read_len)
     return ((rows * cpr + 63u) >> 6) * 1024u + SK_TILE_SLACK; // whole pieces of the loader
 }
 
+#define SK_WIDE_STAGE 16 /* pieces the register stage of the medium-read tiles holds (64 + 16 registers) */
 // 32 reads to a tile while five waves' images still fit a CU (reads up to ~940 bases), 16 beyond (measured: 600 bases 3.5
 // against 2.9 TB/s, 1 000 bases 2.2 against 2.7); SK_WIDE_ROWS=16|32 forces one (A/B runs)
 static uint32_t wide_rows(uint32_t read_len)
@@ -1361,6 +1411,14 @@ static uint32_t wide_rows(uint32_t read_len)
     static const uint32_t forced = [] { const char *e = getenv("SK_WIDE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
     if (forced == 16u || forced == 32u) return forced;
     return wide_image_bytes(32u, read_len) * 5u <= SK_LDS_PER_CU ? 32u : 16u;
+}
+// does the next tile wait in registers?  (no -n, rows 4-byte aligned, an image of at most SK_WIDE_STAGE pieces;
+// SK_WIDE_STAGE=0 in the environment: never -- A/B runs)
+static bool wide_staged(const uint8_t *qual, const sk_scan_args *a, uint32_t rows)
+{
+    static const bool on = [] { const char *e = getenv("SK_WIDE_STAGE"); return !(e && *e == '0'); }();
+    const uint32_t pieces = (wide_image_bytes(rows, a->read_len) - SK_TILE_SLACK) >> 10;
+    return on && !a->truncn && a->stride % 4u == 0 && (reinterpret_cast<uintptr_t>(qual) & 3u) == 0 && pieces <= SK_WIDE_STAGE;
 }
 
 extern "C" __attribute__((visibility("hidden"))) uint32_t sk_wide_lds_bytes(uint32_t read_len)
@@ -1374,11 +1432,17 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
                                      const sk_scan_args *a, int cu_count, hipStream_t stream)
 {
     sk_scan_args aw = *a;
-    aw.buf_bytes = sk_wide_lds_bytes(a->read_len);
-    if (aw.buf_bytes == 0) return hipErrorInvalidValue;
+    if (sk_wide_lds_bytes(a->read_len) == 0) return hipErrorInvalidValue;
+    // 16-read tiles with the next tile in registers where that is to be had (reads up to ~1 000 bases without -n),
+    // else 32- or 16-read tiles by LDS-DMA
+    static const uint32_t forced_rows = [] { const char *e = getenv("SK_WIDE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    // (where seven waves' 32-read images fit a CU -- reads up to ~700 bases -- those win: 600 bases 3.4 against 3.2 TB/s;
+    // beyond, the staged 16-read tiles: 800 bases 3.26 against 2.90, 1 000 bases 3.56 against 3.30)
+    const bool staged = forced_rows != 32u && wide_staged(qual, a, 16u) && (forced_rows == 16u || wide_image_bytes(32u, a->read_len) * 7u > SK_LDS_PER_CU);
+    const uint32_t rows = staged ? 16u : wide_rows(a->read_len);
+    aw.buf_bytes = wide_image_bytes(rows, a->read_len);
     int per_cu = (int)(SK_LDS_PER_CU / aw.buf_bytes);
     if (per_cu > 16) per_cu = 16;
-    const uint32_t rows = wide_rows(a->read_len);
     const uint64_t n_tiles = (a->n_reads + rows - 1) / rows;
     uint64_t grid = (uint64_t)cu_count * per_cu;
     if (grid > n_tiles) grid = n_tiles;
@@ -1389,6 +1453,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
         return hipGetLastError();
     };
+    if (staged) {
+        // (bounded by registers: two waves to a SIMD)
+        if (per_cu > 8) {
+            per_cu = 8;
+            grid = (uint64_t)cu_count * per_cu;
+            if (grid > n_tiles) grid = n_tiles;
+        }
+        return launch(sk_scan_tile_wide_kernel<false, 2, SK_WIDE_STAGE>);
+    }
     if (rows == 32) return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 1>) : launch(sk_scan_tile_wide_kernel<false, 1>);
     return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 2>) : launch(sk_scan_tile_wide_kernel<false, 2>);
 }

@@ -137,12 +137,14 @@ def test_uniform_medium_reads_many_tiles_per_wave(sk_ctx, L, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", ["16", "32"])
-def test_uniform_medium_reads_both_tile_heights(sk_ctx, rows, monkeypatch):
-    """SK_WIDE_ROWS forces 16- or 32-read tiles for every length the medium-read kernel takes."""
+@pytest.mark.parametrize("rows,stage", [("16", "1"), ("16", "0"), ("32", "1")])
+def test_uniform_medium_reads_both_tile_heights(sk_ctx, rows, stage, monkeypatch):
+    """SK_WIDE_ROWS forces 16- or 32-read tiles for every length the medium-read kernel takes; with 16, the next tile
+    waits in registers wherever it can (SK_WIDE_STAGE=0: nowhere)."""
     monkeypatch.setenv("SK_WIDE_ROWS", rows)
+    monkeypatch.setenv("SK_WIDE_STAGE", stage)
     import subprocess, sys as _sys
-    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "soak_wide.py"), "60", "77"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(__file__), "soak_wide.py"), "80", "77"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
