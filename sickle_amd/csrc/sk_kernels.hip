@@ -444,14 +444,15 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         else tile_to_lds(base + v.off, dst, v.bytes, lane);
     };
 
-    // WSTAGE (medium-read tiles without -n whose image has at most WSTAGE 1 KiB pieces, rows 4-byte aligned): the NEXT
+    // WSTAGE (medium-read tiles without -n whose image has at most WSTAGE 1 KiB pieces; rows at any byte address -- the
+    // device's unaligned access mode takes 16-byte loads anywhere, as the LDS-DMA loader's do): the NEXT
     // tile waits in the wave's registers -- plain 16-byte loads at the re-striding loader's addresses, in flight while
     // this tile is scanned, written to LDS (same image) at the top of the next turn.  Every full tile of the launch has
     // the same shape, so a lane's source offsets relative to its tile are computed ONCE (the DMA loader spends ~12 vector
     // instructions a piece on them, tile after tile); the wave no longer waits for its tile after every scan (43 % of
     // its cycles at 1 000 bases), and the loads are plain ones.  The batch's last tiles (fewer rows, or chunks that could
     // leave the caller's buffer) come in by LDS-DMA as before.
-    typedef uint32_t sk_v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t sk_v4u_a4 __attribute__((ext_vector_type(4), aligned(1)));
     uint32_t wso[WSTAGE ? WSTAGE : 1];
     sk_v4u wst[WSTAGE ? WSTAGE : 1];
     const uint32_t wpieces = WSTAGE ? (ROWS * (rag_pitch<true>(a.read_len) / 16u) + 63u) >> 6 : 0u;
@@ -1385,6 +1386,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     };
     const uint32_t wu = a->read_len / 10 ? a->read_len / 10 : a->read_len;
     const bool mfma = uniform && wu <= 65 && a->read_len > 0;
+    // (Tried for packed short reads, reads up to 240 bases back to back: the register stage of the medium-read tiles --
+    // next tile in registers, source offsets computed once.  0.56-0.60 against 0.55-0.62 of peak without it on
+    // packed150: no gain where 14 waves' images fit a CU anyway; not kept.)
     if (a->truncn) {
         if (mfma) return launch(sk_scan_tile_any_kernel<true, true, true>);
         if (uniform) return launch(sk_scan_tile_any_kernel<true, true, false>);
@@ -1412,13 +1416,14 @@ static uint32_t wide_rows(uint32_t read_len)
     if (forced == 16u || forced == 32u) return forced;
     return wide_image_bytes(32u, read_len) * 5u <= SK_LDS_PER_CU ? 32u : 16u;
 }
-// does the next tile wait in registers?  (no -n, rows 4-byte aligned, an image of at most SK_WIDE_STAGE pieces;
+// does the next tile wait in registers?  (no -n, an image of at most SK_WIDE_STAGE pieces;
 // SK_WIDE_STAGE=0 in the environment: never -- A/B runs)
 static bool wide_staged(const uint8_t *qual, const sk_scan_args *a, uint32_t rows)
 {
     static const bool on = [] { const char *e = getenv("SK_WIDE_STAGE"); return !(e && *e == '0'); }();
     const uint32_t pieces = (wide_image_bytes(rows, a->read_len) - SK_TILE_SLACK) >> 10;
-    return on && !a->truncn && a->stride % 4u == 0 && (reinterpret_cast<uintptr_t>(qual) & 3u) == 0 && pieces <= SK_WIDE_STAGE;
+    (void)qual; // (rows at any byte address: the device's unaligned access mode takes 16-byte loads anywhere, as the LDS-DMA loader's do)
+    return on && !a->truncn && pieces <= SK_WIDE_STAGE;
 }
 
 extern "C" __attribute__((visibility("hidden"))) uint32_t sk_wide_lds_bytes(uint32_t read_len)
