@@ -877,6 +877,26 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                 // the FIRST turn: the exit changes the code generated for the steps before it.  Compiler or hazard, not
                 // the algorithm -- not pursued, not done.)
                 const int nsteps = WIDE == 2 ? min(nwinmax, whalf) : nwinmax; // windows a lane walks
+                if (WSTAGE) {
+                    // (the register stage leaves no room for the second set of fragments: read one step ahead only)
+                    frags fa = fetch(0);
+                    sk_v16i da = sums(fa), db = da;
+                    for (int base = 0; base < nsteps; base += 64) {
+                        const int st = base >> 5;
+                        const bool second = base + 32 < nsteps, third = base + 64 < nsteps;
+                        if (second) {
+                            fa = fetch(st + 1);
+                            db = sums(fa);
+                        }
+                        signs(da, base);
+                        if (!second) break;
+                        if (third) {
+                            fa = fetch(st + 2);
+                            da = sums(fa);
+                        }
+                        signs(db, base + 32);
+                    }
+                } else {
                 frags fa = fetch(0), fb = fa;
                 if (32 < nsteps) fb = fetch(1);
                 sk_v16i da = sums(fa), db = da;
@@ -890,6 +910,7 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
                     if (base + 96 < nsteps) fb = fetch(st + 3);
                     if (third) da = sums(fa);
                     signs(db, base + 32);
+                }
                 }
                 if (WIDE == 2) join_halves();
             } else if (SEG == 2 || (SEG != 3 && !three_blocks)) { // w <= 33: positions base .. base+63, two trips per turn so that
@@ -1407,7 +1428,7 @@ static uint32_t wide_image_bytes(uint32_t rows, uint32_t read_len)
     return ((rows * cpr + 63u) >> 6) * 1024u + SK_TILE_SLACK; // whole pieces of the loader
 }
 
-#define SK_WIDE_STAGE 16 /* pieces the register stage of the medium-read tiles holds (64 + 16 registers) */
+#define SK_WIDE_STAGE 20 /* pieces the register stage of the medium-read tiles holds */
 // 32 reads to a tile while five waves' images still fit a CU (reads up to ~940 bases), 16 beyond (measured: 600 bases 3.5
 // against 2.9 TB/s, 1 000 bases 2.2 against 2.7); SK_WIDE_ROWS=16|32 forces one (A/B runs)
 static uint32_t wide_rows(uint32_t read_len)
