@@ -105,7 +105,7 @@ def test_uniform_medium_reads_soak(sk_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,n", [(600, 150_000), (1000, 120_000), (1500, 80_000)])
+@pytest.mark.parametrize("L,n", [(600, 150_000), (1000, 120_000), (1201, 100_000), (1500, 80_000)])
 def test_uniform_medium_reads_many_tiles_per_wave(sk_ctx, L, n):
     """More tiles than the launch has waves (2 304 .. 4 096): every wave goes round its loop several times -- refill
     after the scan, the next tile's first step behind the last one's state -- which tests/soak_wide.py's small batches
