@@ -41,7 +41,7 @@
  *                 ...: the rows then spread over all LDS banks; stride/8 even still works, slower).
  *                 Any other stride <= SK_TILE_MAX_STRIDE or alignment (e.g. reads packed back to
  *                 back, stride == read_len) is re-strided like a ragged batch; longer rows: one
- *                 length (lengths == NULL) of up to ~1900 bases keeps the tile kernel with 32 or 16
+ *                 length (lengths == NULL) of up to ~2200 bases keeps the tile kernel with 32 or 16
  *                 reads to a tile (round 3), anything else goes through the general kernels.
  *   segmented   : tiles != NULL (offsets and lengths NULL).  The caller has grouped the reads
  *                 by length: tile t holds `rows` (<= 64) reads of `read_len` bytes each at
@@ -213,7 +213,7 @@ int sk_wait(sk_ctx *ctx, int slot, sk_err *err);
 uint32_t sk_seg_classes(const sk_tile *tiles, uint32_t n_tiles, sk_seg_class *out, uint32_t max_classes);
 
 /* Which kernel a batch of this shape would use: 1 = tiled (lane per read, LDS tile by LDS-DMA),
- * 8 = uniform medium reads (fixed stride, one length of ~505 .. 1900 bases: tiles of 32 or 16 reads, a pair / four lanes
+ * 8 = uniform medium reads (fixed stride, one length of ~505 .. 2200 bases: tiles of 32 or 16 reads, a pair / four lanes
  * per read, windows of any width on the matrix path), 2 = general, medium reads (teams of 16 lanes per read, up to a
  * longest read of 4096: ragged medium reads, uniform ones beyond 8's range), 6 = general, long reads (a
  * wave per read with the read streamed through LDS), 3 = tiled over a segmented batch, 4 = tiled with the tile

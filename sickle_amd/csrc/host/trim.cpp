@@ -493,7 +493,7 @@ void Abstract_Trimmer::submit_scan(int slot, Span<FQEntry> reads)
     // inside, so the batch stays on the same fast path with no padding to the longest read, and
     // the device scatters the cuts back to input order (out_index).  Longer reads of ONE length (up
     // to 4 096 bases): back to back at a fixed stride = their length -- the library's medium-read tiles
-    // take those up to ~1 900 bases on the matrix path, its general kernels the rest.  Anything else:
+    // take those up to ~2 200 bases on the matrix path, its general kernels the rest.  Anything else:
     // packed back to back with an offsets array -> the general kernels.
     size_t total_len = 0, max_len = 0;
     bool uniform = true;

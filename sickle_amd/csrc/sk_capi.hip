@@ -230,7 +230,7 @@ hipError_t launch_general(const uint8_t *qual, const uint8_t *seq, const uint64_
 bool wide_takes(const sk_batch *b)
 {
     if (b->offsets || b->lengths || b->tiles || getenv("SK_GENERAL")) return false;
-    static const uint32_t wide_max = [] { const char *e = getenv("SK_WIDE_MAX"); return e ? (uint32_t)atoi(e) : 1900u; }();
+    static const uint32_t wide_max = [] { const char *e = getenv("SK_WIDE_MAX"); return e ? (uint32_t)atoi(e) : 2200u; }();
     return b->read_len <= wide_max && b->stride < (1u << 24) && sk_wide_lds_bytes(b->read_len) != 0; // (the loader's 24-bit row offsets)
 }
 

@@ -372,6 +372,30 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     };
     auto index_settle = [&](uint32_t &idx) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx)::"memory"); };
 
+    // WIDE: every full tile of a launch has the same shape, so a lane's source offsets relative to its tile -- what the
+    // re-striding loader spends ~12 vector instructions a piece on -- are computed ONCE: WOFF of them (the register stage
+    // loads from them, the LDS-DMA loader of the other medium-read kernels issues its pieces from them).
+    typedef uint32_t sk_v4u_a4 __attribute__((ext_vector_type(4), aligned(1)));
+    constexpr int WOFF = WIDE ? (WSTAGE ? WSTAGE : 32) : 0;
+    uint32_t wso[WOFF ? WOFF : 1];
+    sk_v4u wst[WSTAGE ? WSTAGE : 1];
+    const uint32_t wpieces = WIDE ? (ROWS * (rag_pitch<true>(a.read_len) / 16u) + 63u) >> 6 : 0u;
+    if (WIDE) {
+        const uint32_t cpr = rag_pitch<true>(a.read_len) / 16u, qd = 64u / cpr, rd = 64u % cpr;
+        const uint32_t lim = (ROWS - 1u) * stride + a.read_len - 1u;
+        uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
+#pragma unroll
+        for (int p = 0; p < WOFF; ++p) {
+            wso[p] = min(__umul24(rr, stride) + 16u * cc, lim);
+            cc += rd;
+            rr += qd;
+            if (cc >= cpr) {
+                cc -= cpr;
+                ++rr;
+            }
+        }
+    }
+
     // the re-striding loader (RAG): image chunk 64p + lane = (row, c) = divmod(64p + lane, chunks per row)
     // comes from the row's start + c chunks.  Chunks beyond a row's end fetch what follows it in the batch (nobody
     // reads them); the clamp keeps those inside the tile (a row's last chunk may still reach up to 15
@@ -385,6 +409,13 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
         const uint32_t lim = (v.bytes ? v.bytes : 1u) - 1u;
         // (a tile whose last byte is followed by 16 more of the batch: no chunk of it can leave the caller's buffer)
         const bool all_safe = v.off + (uint64_t)lim + 1u + GRAN <= batch_end; // wave-uniform
+        if (WIDE && !WSTAGE && all_safe && v.rows == ROWS && wpieces <= (uint32_t)WOFF) {
+            // a full tile inside the batch: the pieces from the offsets computed at the start of the launch
+#pragma unroll
+            for (int p = 0; p < WOFF; ++p)
+                if ((uint32_t)p < wpieces) dma_piece<true, false>(src + wso[p], dst + (uint32_t)p * (64u * GRAN));
+            return;
+        }
         // one piece: its chunks start `ro` bytes into the tile (a row start per lane) + GRAN * cc
         auto piece = [&](uint32_t p, uint32_t ro, uint32_t cc_p) {
             const uint32_t so = min(ro + GRAN * cc_p, lim);
@@ -452,25 +483,6 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
     // instructions a piece on them, tile after tile); the wave no longer waits for its tile after every scan (43 % of
     // its cycles at 1 000 bases), and the loads are plain ones.  The batch's last tiles (fewer rows, or chunks that could
     // leave the caller's buffer) come in by LDS-DMA as before.
-    typedef uint32_t sk_v4u_a4 __attribute__((ext_vector_type(4), aligned(1)));
-    uint32_t wso[WSTAGE ? WSTAGE : 1];
-    sk_v4u wst[WSTAGE ? WSTAGE : 1];
-    const uint32_t wpieces = WSTAGE ? (ROWS * (rag_pitch<true>(a.read_len) / 16u) + 63u) >> 6 : 0u;
-    if (WSTAGE) {
-        const uint32_t cpr = rag_pitch<true>(a.read_len) / 16u, qd = 64u / cpr, rd = 64u % cpr;
-        const uint32_t lim = (ROWS - 1u) * stride + a.read_len - 1u;
-        uint32_t rr = (uint32_t)lane / cpr, cc = (uint32_t)lane % cpr;
-#pragma unroll
-        for (int p = 0; p < WSTAGE; ++p) {
-            wso[p] = min(__umul24(rr, stride) + 16u * cc, lim);
-            cc += rd;
-            rr += qd;
-            if (cc >= cpr) {
-                cc -= cpr;
-                ++rr;
-            }
-        }
-    }
     auto wstage_ok = [&](const sk_tile_view &v) -> bool { return WSTAGE && v.rows == ROWS && v.off + (uint64_t)v.bytes + 16u <= batch_end; };
     auto wstage_load = [&](const sk_tile_view &v) {
         const uint8_t *src = qual + v.off;
@@ -830,7 +842,6 @@ sk_scan_tile_body(const uint8_t *__restrict__ qual, const uint8_t *__restrict__ 
             if (WIDE) {
                 // one group of 32 reads; lane (n, half): 16 bytes of read n at positions 32 * block + 16 * half
                 const int dm = wu / 32 - 1;      // blocks every window of a step covers whole (wu >= 32)
-                const int far = 32 * (dm + 1);   // the first of the two blocks with the band's far edge
                 const sk_v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101}, minus = {-1, -1, -1, -1};
                 sk_v16i mid = negT; // -T + the whole blocks of the step
                 auto frag = [&](int blk) -> sk_v4i { return load_frag(frag0 + 32 * blk); };
@@ -1476,18 +1487,16 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
     auto launch = [&](auto kern) {
         const kernel_facts facts = prepare_kernel(kern);
         if (facts.status != hipSuccess) return facts.status;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
+        // the grid is persistent: workgroups beyond what a CU's registers hold would run as a second round, a wave to a CU
+        const int regs = facts.regs > 0 ? facts.regs : 256;
+        int fits = 4 * (512 / ((regs + 7) & ~7));
+        if (fits < 4) fits = 4;
+        uint64_t g = (uint64_t)cu_count * (per_cu < fits ? per_cu : fits);
+        if (g > n_tiles) g = n_tiles;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
         return hipGetLastError();
     };
-    if (staged) {
-        // (bounded by registers: two waves to a SIMD)
-        if (per_cu > 8) {
-            per_cu = 8;
-            grid = (uint64_t)cu_count * per_cu;
-            if (grid > n_tiles) grid = n_tiles;
-        }
-        return launch(sk_scan_tile_wide_kernel<false, 2, SK_WIDE_STAGE>);
-    }
+    if (staged) return launch(sk_scan_tile_wide_kernel<false, 2, SK_WIDE_STAGE>);
     if (rows == 32) return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 1>) : launch(sk_scan_tile_wide_kernel<false, 1>);
     return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 2>) : launch(sk_scan_tile_wide_kernel<false, 2>);
 }
