@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <algorithm>
 
 #include "sk_device.h"
 
@@ -466,6 +467,14 @@ struct kernel_facts {
     hipError_t status = hipSuccess;
     int regs = 0;
 };
+// single-wave workgroups a CU's registers hold of a kernel (512 per lane and SIMD, allocated in eights, four SIMDs).  The
+// tile kernels' grids are persistent: a workgroup beyond that would run as a second round, a wave to a CU.
+inline int reg_fit(const kernel_facts &f)
+{
+    const int regs = f.regs > 0 ? f.regs : 256;
+    const int fits = 4 * (512 / ((regs + 7) & ~7));
+    return fits < 4 ? 4 : fits;
+}
 template <typename K>
 kernel_facts prepare_kernel(K kern)
 {

@@ -1263,14 +1263,12 @@ hipError_t launch_tile_kernel(K kern, int bufs, const uint8_t *qual, const uint8
     if (per_cu > 16) per_cu = 16;
     const kernel_facts facts = prepare_kernel(kern);
     if (facts.status != hipSuccess) return facts.status;
-    if (by_registers) {
+    {
         // the staged kernels are bounded by their registers, not by LDS (the grid is persistent, so
         // workgroups beyond what fits would only run as a second round): waves per SIMD = the 512
         // registers of a lane's file over the kernel's count (allocated in eights), four SIMDs
-        const int regs = facts.regs > 0 ? facts.regs : 160;
-        int fits = 4 * (512 / ((regs + 7) & ~7));
-        if (fits < 4) fits = 4;
-        if (getenv("SK_DEBUG_LAUNCH")) fprintf(stderr, "[sk] staged kernel: %d registers -> %d workgroups per CU\n", regs, fits);
+        const int fits = reg_fit(facts);
+        if (by_registers && getenv("SK_DEBUG_LAUNCH")) fprintf(stderr, "[sk] staged kernel: %d registers -> %d workgroups per CU\n", facts.regs, fits);
         if (per_cu > fits) per_cu = fits;
     }
     if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
@@ -1369,8 +1367,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_seg(const 
             const kernel_facts facts = prepare_kernel(kern);
             if (facts.status != hipSuccess) return facts.status;
             uint64_t g = grid;
-            if (wg_per_cu > 0 && wg_per_cu < per_cu) { // bounded by registers, not by LDS
-                g = (uint64_t)cu_count * wg_per_cu;
+            const int fit = wg_per_cu > 0 ? std::min(wg_per_cu, reg_fit(facts)) : reg_fit(facts);
+            if (fit < per_cu) { // bounded by registers, not by LDS
+                g = (uint64_t)cu_count * fit;
                 if (g > chunks) g = chunks;
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), lds_bytes, stream, qual, seq,
@@ -1412,7 +1411,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_any(const 
     auto launch = [&](auto kern) {
         const kernel_facts facts = prepare_kernel(kern);
         if (facts.status != hipSuccess) return facts.status;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
+        uint64_t g = (uint64_t)cu_count * std::min(per_cu, reg_fit(facts)); // (LDS and registers)
+        if (g > n_tiles) g = n_tiles;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), lds_bytes, stream, qual, seq, offsets, lengths, out,
                            errword, *a);
         return hipGetLastError();
     };
@@ -1488,10 +1489,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
         const kernel_facts facts = prepare_kernel(kern);
         if (facts.status != hipSuccess) return facts.status;
         // the grid is persistent: workgroups beyond what a CU's registers hold would run as a second round, a wave to a CU
-        const int regs = facts.regs > 0 ? facts.regs : 256;
-        int fits = 4 * (512 / ((regs + 7) & ~7));
-        if (fits < 4) fits = 4;
-        uint64_t g = (uint64_t)cu_count * (per_cu < fits ? per_cu : fits);
+        uint64_t g = (uint64_t)cu_count * std::min(per_cu, reg_fit(facts));
         if (g > n_tiles) g = n_tiles;
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
         return hipGetLastError();
@@ -1518,7 +1516,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_sorted(con
     auto launch = [&](auto kern) {
         const kernel_facts facts = prepare_kernel(kern);
         if (facts.status != hipSuccess) return facts.status;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, stream, qual, seq, offsets, perm, lists, counts, out, errword, *a);
+        uint64_t g = ((uint64_t)cu_count * std::min(per_cu, reg_fit(facts))) & ~7ull; // (LDS and registers; the same number of workgroups for every list)
+        if (g > grid) g = grid;
+        if (g < 8) g = 8;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), lds_bytes, stream, qual, seq, offsets, perm, lists, counts, out, errword, *a);
         return hipGetLastError();
     };
     return a->truncn ? launch(sk_scan_tile_sorted_kernel<true>) : launch(sk_scan_tile_sorted_kernel<false>);
