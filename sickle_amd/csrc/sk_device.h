@@ -16,7 +16,9 @@
 #define SK_RAG_MAX_LEN 2040            /* longest read the lane-per-read kernel takes from a ragged batch */
 #define SK_RAG_BUF_DEFAULT (20u * 1024u) /* LDS bytes per wave for ragged tiles when the caller gives no length hint */
 #define SK_RAG_BUF_MAX (40u * 1024u)
+#ifndef SK_SORT_WINDOW
 #define SK_SORT_WINDOW 8192  /* reads per window of the device-side regrouping of mixed-length ragged batches (sk_sort.hip) */
+#endif
 #define SK_SORT_MIN_READS 65536u /* ragged batches below this keep the plain tile kernel */
 
 struct sk_cut_dev {
