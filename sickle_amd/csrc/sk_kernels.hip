@@ -1476,8 +1476,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
     static const uint32_t forced_rows = [] { const char *e = getenv("SK_WIDE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
     // (where seven waves' 32-read images fit a CU -- reads up to ~700 bases -- those win: 600 bases 3.4 against 3.2 TB/s;
     // beyond, the staged 16-read tiles: 800 bases 3.26 against 2.90, 1 000 bases 3.56 against 3.30)
-    const bool staged = forced_rows != 32u && wide_staged(qual, a, 16u) && (forced_rows == 16u || wide_image_bytes(32u, a->read_len) * 7u > SK_LDS_PER_CU);
-    const uint32_t rows = staged ? 16u : wide_rows(a->read_len);
+    // (SK_WIDE_STAGE32=0: never the 32-read stage -- A/B runs)
+    static const bool stage32_on = [] { const char *e = getenv("SK_WIDE_STAGE32"); return !(e && *e == '0'); }();
+    const bool staged32 = stage32_on && forced_rows != 16u && wide_staged(qual, a, 32u); // reads up to ~624 bases: 32-read tiles of up to 20 pieces
+    const bool staged = !staged32 && forced_rows != 32u && wide_staged(qual, a, 16u) && (forced_rows == 16u || wide_image_bytes(32u, a->read_len) * 7u > SK_LDS_PER_CU);
+    const uint32_t rows = staged32 ? 32u : staged ? 16u : wide_rows(a->read_len);
     aw.buf_bytes = wide_image_bytes(rows, a->read_len);
     int per_cu = (int)(SK_LDS_PER_CU / aw.buf_bytes);
     if (per_cu > 16) per_cu = 16;
@@ -1494,6 +1497,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t sk_launch_wide(const
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64), aw.buf_bytes, stream, qual, seq, out, errword, aw);
         return hipGetLastError();
     };
+    if (staged32) return launch(sk_scan_tile_wide_kernel<false, 1, SK_WIDE_STAGE>);
     if (staged) return launch(sk_scan_tile_wide_kernel<false, 2, SK_WIDE_STAGE>);
     if (rows == 32) return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 1>) : launch(sk_scan_tile_wide_kernel<false, 1>);
     return a->truncn ? launch(sk_scan_tile_wide_kernel<true, 2>) : launch(sk_scan_tile_wide_kernel<false, 2>);

@@ -137,7 +137,7 @@ def test_uniform_medium_reads_many_tiles_per_wave(sk_ctx, L, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,stage", [("16", "1"), ("16", "0"), ("32", "1")])
+@pytest.mark.parametrize("rows,stage", [("16", "1"), ("16", "0"), ("32", "1"), ("32", "0")])
 def test_uniform_medium_reads_both_tile_heights(sk_ctx, rows, stage, monkeypatch):
     """SK_WIDE_ROWS forces 16- or 32-read tiles for every length the medium-read kernel takes; with 16, the next tile
     waits in registers wherever it can (SK_WIDE_STAGE=0: nowhere)."""
