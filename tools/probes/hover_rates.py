@@ -21,14 +21,15 @@ hover = (53 + torch.randint(-1, 2, (total + 65536,), device=dev, generator=g)).t
 sustain = (53 + (torch.arange(total + 65536, device=dev) & 1)).to(torch.uint8)  # averages Q20.5 against -q 20 from end to end: never below, every cell flagged
 torch.cuda.synchronize()
 def timeit(fn, reps=10):
-    for _ in range(20): fn()
+    for _ in range(60): fn()
     s.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for e0, e1 in evs:
         e0.record(s); fn(); e1.record(s)
     s.synchronize()
     return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
-for L in (4000, 5000, 10_000, 30_000):
+LENS = tuple(int(x) for x in sys.argv[1:]) or (4000, 5000, 10_000, 30_000)  # (600 1000 1500: the medium-read tiles)
+for L in LENS:
     n = total // L
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     res = {}
